@@ -1,0 +1,135 @@
+/* gpk.h -- C ABI of libgpk.so: the MI355X (gfx950) implementation of the Gram-assembly + Gauss-Newton hot path of
+ * yifanc96/NonLinPDEs-GPsolver.  The reference has no FFI of its own (it is pure Python on JAX); the boundary this
+ * library replaces is the set of array-level operations its src/ modules hand to XLA.  Each entry point names the
+ * reference call site(s) it stands in for (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - return int: 0 ok; >0 LAPACK-style info (1-based index of the first non-positive pivot); <0 = -(hipError_t),
+ *     text via gpk_last_error().  -9001 = invalid argument, -9002 = library built without a usable device.
+ *   - every matrix/vector pointer is a DEVICE pointer owned by the caller unless the name says `host`; the library
+ *     never frees or keeps them after the call.  Matrices are row-major double with a leading dimension in ELEMENTS;
+ *     symmetric outputs are stored full.  Vector loads are 16-byte wide when pointer and leading dimension allow
+ *     (even ld, 16-byte aligned base); any alignment is accepted.
+ *   - calls are asynchronous on the handle's stream; functions that return host scalars (info, loss, ratios)
+ *     synchronise that stream.  One host thread per handle; no global mutable state.
+ *   - there is NO CPU fallback: without a gfx950 device gpk_create fails.
+ */
+#ifndef GPK_H
+#define GPK_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpk_ctx* gpk_handle;
+
+/* Gram layouts = the `eqn` strings of src/Gram_matrice.py:41,58,100,137 (Darcy yields two matrices: _U and _A). */
+enum { GPK_LAYOUT_ELLIPTIC = 0, GPK_LAYOUT_BURGERS = 1, GPK_LAYOUT_EIKONAL = 2, GPK_LAYOUT_DARCY_U = 2, GPK_LAYOUT_DARCY_A = 3 };
+/* kernel classes of src/kernels.py:8,91 */
+enum { GPK_KERNEL_GAUSSIAN = 0, GPK_KERNEL_ANISOTROPIC = 1 };
+/* nugget_type of src/PDEs.py:56,250,391 / src/InverseProblems.py:66 */
+enum { GPK_NUGGET_NONE = 0, GPK_NUGGET_IDENTITY = 1, GPK_NUGGET_ADAPTIVE = 2 };
+/* Gauss-Newton systems (measurement vector F(z) and Jacobian A(z) of each equation class) */
+enum { GPK_GN_ELLIPTIC = 0, GPK_GN_BURGERS = 1, GPK_GN_EIKONAL = 2, GPK_GN_DARCY = 3, GPK_GN_ELLIPTIC_RELAXED = 4 };
+
+/* ---- context, memory, stream ------------------------------------------------------------------------------ */
+int gpk_create(int device, gpk_handle* out);
+int gpk_destroy(gpk_handle h);
+const char* gpk_last_error(gpk_handle h);
+const char* gpk_version(void);
+int gpk_set_stream(gpk_handle h, void* hip_stream);          /* NULL = the handle's own stream */
+int gpk_synchronize(gpk_handle h);
+int gpk_device_info(gpk_handle h, char* name, int name_len, int* compute_units, size_t* hbm_bytes, int* clock_khz);
+int gpk_malloc(gpk_handle h, size_t bytes, void** dptr);
+int gpk_free(gpk_handle h, void* dptr);
+int gpk_memset(gpk_handle h, void* dptr, int value, size_t bytes);
+int gpk_memcpy_h2d(gpk_handle h, void* dst, const void* host_src, size_t bytes);
+int gpk_memcpy_d2h(gpk_handle h, void* host_dst, const void* src, size_t bytes);
+int gpk_memcpy_d2d(gpk_handle h, void* dst, const void* src, size_t bytes);
+int gpk_memcpy2d_h2d(gpk_handle h, void* dst, size_t dpitch, const void* host_src, size_t spitch, size_t width, size_t height);
+int gpk_memcpy2d_d2h(gpk_handle h, void* host_dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
+int gpk_memcpy2d_d2d(gpk_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height);
+
+/* HIP-event stopwatch on the handle's stream (used by bench.py for per-kernel durations). */
+int gpk_timer_start(gpk_handle h);
+int gpk_timer_stop(gpk_handle h, double* host_ms);            /* synchronises */
+
+/* ---- Gram assembly: replaces Gram_matrix_assembly (src/Gram_matrice.py:11-187) plus the nugget of
+ *      *.Gram_matrix (src/PDEs.py:56-73,250-269,391-409; src/InverseProblems.py:66-99) in one fused pass.
+ *      kparams: Gaussian {sigma, unused}; anisotropic {sigma_t, sigma_x}.  Xd (Nd,2), Xb (Nb,2) row-major.
+ *      Theta: N x N, N = 2Nd+Nb (ELLIPTIC), 4Nd+Nb (BURGERS/EIKONAL/DARCY_U), 3Nd (DARCY_A).
+ *      host_ratios[3]: adaptive trace ratios (unused entries 0). */
+int gpk_assemble(gpk_handle h, int layout, int kernel, const double* host_kparams,
+                 const double* Xd, int Nd, const double* Xb, int Nb,
+                 double nugget, int nugget_type, double* Theta, int ld, double* host_ratios);
+/* construct_Theta_test (src/Gram_matrice.py:190-289): out is Nt x N row-major. */
+int gpk_assemble_test(gpk_handle h, int layout, int kernel, const double* host_kparams,
+                      const double* Xt, int Nt, const double* Xd, int Nd, const double* Xb, int Nb,
+                      double* out, int ld);
+/* Theta_test @ coeff without materialising Theta_test: the matmul of *.extend_sol
+ * (src/PDEs.py:208,350,505; src/InverseProblems.py:193,196).  coeff (N,), out (Nt,). */
+int gpk_extend(gpk_handle h, int layout, int kernel, const double* host_kparams,
+               const double* Xt, int Nt, const double* Xd, int Nd, const double* Xb, int Nb,
+               const double* coeff, double* out);
+
+/* ---- dense fp64 linear algebra on the MFMA units --------------------------------------------------------- */
+/* jnp.linalg.cholesky (src/PDEs.py:77,273,413; src/InverseProblems.py:102-103): lower factor in place (strict
+ * upper triangle left untouched -- gpk_tril zeroes it).  Non-positive pivot: *host_info = its 1-based index,
+ * NaNs propagate like the reference's JAX path; return value 0 unless a HIP error occurred. */
+int gpk_potrf(gpk_handle h, double* A, int n, int lda, int* host_info);
+int gpk_tril(gpk_handle h, double* A, int n, int lda);
+int gpk_symmetrize_lower(gpk_handle h, double* A, int n, int lda);   /* copy lower triangle into the upper */
+/* jnp.linalg.solve(self.L, .) with the triangular factor (src/PDEs.py:86,97,143,161,288,306,429,450;
+ * src/InverseProblems.py:118-119,145-146): B <- L^{-1} B (trans=0) or L^{-T} B (trans=1); B is n x nrhs. */
+int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+/* B <- L^{-T} L^{-1} B (src/PDEs.py:205,347,502; src/InverseProblems.py:190,195) */
+int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+/* C <- alpha*op(A)*op(B) + beta*C; ta/tb = 1 means the operand is stored transposed (op(A) is m x k). */
+int gpk_gemm(gpk_handle h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
+             const double* B, int ldb, double beta, double* C, int ldc);
+/* C <- alpha*A^T A + beta*C, A is k x n row-major; lower triangle only unless full != 0
+ * (the 2*ss^T ss of src/PDEs.py:307 and of every autodiff Hessian_GN). */
+int gpk_syrk(gpk_handle h, int n, int k, double alpha, const double* A, int lda, double beta, double* C, int ldc, int full);
+
+/* ---- Gauss-Newton ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int system;              /* GPK_GN_* */
+    int Nd, Nb, Ndata;
+    double p0, p1;           /* ELLIPTIC(_RELAXED): alpha, m   BURGERS: alpha, nu   EIKONAL: eps, -   DARCY: noise_level, - */
+    double pen_lambda;       /* ELLIPTIC_RELAXED only */
+    const double* rhs_f;     /* (Nd,)  */
+    const double* bdy_g;     /* (Nb,)  */
+    const double* data_u;    /* (Ndata,) DARCY only */
+    const double* L;  int ldl;     /* factor of Theta (DARCY: L_u) */
+    const double* L2; int ldl2;    /* DARCY: L_a */
+} gpk_gn_problem;
+
+/* sizes: nz unknowns, rows of the stacked S = [L^{-1}A | L^{-1}F] buffer */
+int gpk_gn_dims(const gpk_gn_problem* host_prob, int* nz, int* s_rows);
+/* One Gauss-Newton step = Hessian_GN + grad_loss + linear solve + update (src/PDEs.py:117-119,322-325,472-475;
+ * src/InverseProblems.py:164-166) and the loss of the INPUT iterate (src/PDEs.py:82-87 ...):
+ *   S  = [L^{-1}A(z) | L^{-1}F(z)]                (s_rows x (nz+1), ld lds)
+ *   Hb = S^T S  (bordered: H/2, g/2, loss)        ((nz+1) x (nz+1), ld ldh)
+ *   z <- z - step * H^{-1} g                       via Cholesky of Hb
+ * host_loss_in = loss(z_in); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g. */
+int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double step_size,
+                double* S, int lds, double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);
+/* loss(z) (src/PDEs.py:82-87,278-289,418-430,138-147; src/InverseProblems.py:105-120); work: s_rows doubles. */
+int gpk_gn_loss(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* work, double* host_loss);
+/* Hessian_GN(z,z) and grad_loss(z) as the reference returns them (full symmetric H = 2 A^T Theta^{-1} A, g);
+ * H is nz x nz with ld ldh (needs (nz+1) x ldh storage, ldh >= nz+1), g (nz,). */
+int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* host_prob, const double* z,
+                        double* S, int lds, double* H, int ldh, double* g);
+/* measurement vector(s) F(z) = sol_vec (src/PDEs.py:132-134,338-342,488-497; IP.py:176-186): out (s_rows,) */
+int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* out);
+
+/* ---- micro-benchmarks used to fix the roofline denominators ------------------------------------------------ */
+int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops);      /* v_mfma_f64_16x16x4_f64 issue rate */
+int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, double* host_gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_H */
