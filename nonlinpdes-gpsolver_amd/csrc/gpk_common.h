@@ -1,0 +1,52 @@
+// gpk_common.h -- internal declarations shared by the libgpk translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include "../../include/gpk.h"
+
+#define GPK_ERR_ARG (-9001)
+#define GPK_ERR_NODEV (-9002)
+
+struct gpk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int* d_info = nullptr;          // device int: first non-positive pivot (1-based), 0 = none
+    double* d_scalars = nullptr;    // small device scratch for reductions (16 doubles)
+    double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
+    size_t pts_cap = 0;
+    int num_cu = 256;
+    std::string err;
+};
+
+int gpk_fail(gpk_handle h, hipError_t e, const char* what, const char* file, int line);
+int gpk_bad_arg(gpk_handle h, const char* what);
+
+#define GPK_HIP(h, call)                                                          \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) return gpk_fail((h), e__, #call, __FILE__, __LINE__); \
+    } while (0)
+#define GPK_TRY(expr)               \
+    do {                            \
+        int r__ = (expr);           \
+        if (r__ != 0) return r__;   \
+    } while (0)
+#define GPK_LAUNCH_CHECK(h) GPK_HIP((h), hipGetLastError())
+
+// ---- internal (stream-ordered, no host sync) building blocks -------------------------------------------------
+// C <- alpha*op(A)*op(B) + beta*C.  lower_only: skip tiles strictly above the diagonal (square C).
+int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only);
+int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
+int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);
+int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x);   // x contiguous
+int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_out);    // d_out device scalar
+int gpk_i_ensure_points(gpk_handle h, size_t doubles);
+
+static inline int gpk_ceil_div(int a, int b) { return (a + b - 1) / b; }

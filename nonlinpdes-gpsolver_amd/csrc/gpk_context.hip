@@ -1,0 +1,165 @@
+// gpk_context.hip -- handle, memory, stream and stopwatch entry points of the C ABI.
+#include "gpk_common.h"
+
+int gpk_fail(gpk_handle h, hipError_t e, const char* what, const char* file, int line) {
+    if (h) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+        h->err = buf;
+    }
+    return -(int)e;
+}
+
+int gpk_bad_arg(gpk_handle h, const char* what) {
+    if (h) h->err = std::string("invalid argument: ") + what;
+    return GPK_ERR_ARG;
+}
+
+extern "C" const char* gpk_version(void) { return "gpk 0.1 (gfx950, fp64 MFMA)"; }
+
+extern "C" int gpk_create(int device, gpk_handle* out) {
+    if (!out) return GPK_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GPK_ERR_NODEV;   // no CPU fallback
+    if (device < 0 || device >= count) return GPK_ERR_ARG;
+    gpk_ctx* h = new gpk_ctx();
+    h->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_info, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, 64 * sizeof(double));
+    if (e == hipSuccess) e = hipMemset(h->d_info, 0, sizeof(int));
+    if (e != hipSuccess) { delete h; return -(int)e; }
+    h->stream = h->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+    *out = h;
+    return 0;
+}
+
+extern "C" int gpk_destroy(gpk_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (h->d_info) hipFree(h->d_info);
+    if (h->d_scalars) hipFree(h->d_scalars);
+    if (h->d_pts) hipFree(h->d_pts);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return 0;
+}
+
+extern "C" const char* gpk_last_error(gpk_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int gpk_set_stream(gpk_handle h, void* s) {
+    if (!h) return GPK_ERR_ARG;
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return 0;
+}
+
+extern "C" int gpk_synchronize(gpk_handle h) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int gpk_device_info(gpk_handle h, char* name, int name_len, int* cus, size_t* hbm, int* clock_khz) {
+    if (!h) return GPK_ERR_ARG;
+    hipDeviceProp_t prop;
+    GPK_HIP(h, hipGetDeviceProperties(&prop, h->device));
+    if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = prop.totalGlobalMem;
+    if (clock_khz) *clock_khz = prop.clockRate;
+    return 0;
+}
+
+extern "C" int gpk_malloc(gpk_handle h, size_t bytes, void** dptr) {
+    if (!h || !dptr) return GPK_ERR_ARG;
+    GPK_HIP(h, hipSetDevice(h->device));
+    GPK_HIP(h, hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+
+extern "C" int gpk_free(gpk_handle h, void* dptr) {
+    if (!h) return GPK_ERR_ARG;
+    if (!dptr) return 0;
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    GPK_HIP(h, hipFree(dptr));
+    return 0;
+}
+
+extern "C" int gpk_memset(gpk_handle h, void* dptr, int value, size_t bytes) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemsetAsync(dptr, value, bytes, h->stream));
+    return 0;
+}
+
+// Host buffers handed over by ctypes are pageable: the copies are synchronous w.r.t. the host buffer.
+extern "C" int gpk_memcpy_h2d(gpk_handle h, void* dst, const void* src, size_t bytes) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int gpk_memcpy_d2h(gpk_handle h, void* dst, const void* src, size_t bytes) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int gpk_memcpy_d2d(gpk_handle h, void* dst, const void* src, size_t bytes) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+extern "C" int gpk_memcpy2d_h2d(gpk_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    if (!h) return GPK_ERR_ARG;
+    if (width == 0 || height == 0) return 0;
+    GPK_HIP(h, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyHostToDevice, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int gpk_memcpy2d_d2h(gpk_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    if (!h) return GPK_ERR_ARG;
+    if (width == 0 || height == 0) return 0;
+    GPK_HIP(h, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+extern "C" int gpk_memcpy2d_d2d(gpk_handle h, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height) {
+    if (!h) return GPK_ERR_ARG;
+    if (width == 0 || height == 0) return 0;
+    GPK_HIP(h, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+extern "C" int gpk_timer_start(gpk_handle h) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+extern "C" int gpk_timer_stop(gpk_handle h, double* ms) {
+    if (!h || !ms) return GPK_ERR_ARG;
+    GPK_HIP(h, hipEventRecord(h->ev1, h->stream));
+    GPK_HIP(h, hipEventSynchronize(h->ev1));
+    float f = 0.f;
+    GPK_HIP(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
+    *ms = (double)f;
+    return 0;
+}
+
+int gpk_i_ensure_points(gpk_handle h, size_t doubles) {
+    if (h->pts_cap >= doubles) return 0;
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->d_pts) GPK_HIP(h, hipFree(h->d_pts));
+    h->d_pts = nullptr; h->pts_cap = 0;
+    GPK_HIP(h, hipMalloc((void**)&h->d_pts, doubles * sizeof(double)));
+    h->pts_cap = doubles;
+    return 0;
+}

@@ -1,0 +1,277 @@
+// gpk_gemm.hip -- fp64 GEMM/SYRK on the CDNA4 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// The one contraction kernel behind every O(n^3) step of the path: the SYRK H = S^T S of Hessian_GN
+// (reference src/PDEs.py:100-102,295-307,453-455; src/InverseProblems.py:149-151), the trailing updates of the
+// Cholesky factorisation (jnp.linalg.cholesky, src/PDEs.py:77,273,413) and the off-diagonal updates of the
+// triangular solves (jnp.linalg.solve(self.L, .), src/PDEs.py:86,97,...).
+//
+// C[m,n] <- alpha * sum_k opA[m,k] opB[k,n] + beta * C[m,n], everything row-major fp64.
+//   TA = false: A stored [m][k] (k contiguous)      TA = true: A stored [k][m] (m contiguous)
+//   TB = false: B stored [k][n] (n contiguous)      TB = true: B stored [n][k] (k contiguous)
+//
+// Tiling for wave64 / MFMA 16x16x4 f64 (one instruction = 2048 flop, 64 cycles on a SIMD):
+//   workgroup = 4 waves in a 2x2 grid, wave tile WM x WN = (WM/16) x (WN/16) MFMA accumulators (4 f64/lane each);
+//   K is consumed in slabs of BK = 16 staged through LDS, double-buffered, global->register prefetch of slab t+1
+//   issued before the MFMAs of slab t (one barrier per slab).
+//   LDS images are padded so that every ds_read_b64 of a fragment is bank-conflict free:
+//     k-contiguous operand : [row][BK+2]   (144-byte rows: 16 rows x 2 k's hit 32 distinct 8-byte bank pairs)
+//     m-contiguous operand : [k][BM+16]    (consecutive k rows offset by 128 bytes mod 256)
+//   MFMA operand map (cdna_hip_programming.md:247-251): A lane l = A[l&15][k=l>>4], B lane l = B[k=l>>4][l&15],
+//   C/D lane l reg r = C[(l>>4)+4r][l&15].
+// Workgroup -> tile map is XCD-aware: hardware places block b on XCD b%8, so logical tile ids are handed out in
+// 8 contiguous chunks (one per XCD L2), ordered in groups of 8 tile rows so that a chunk re-uses its A/B panels.
+#include "gpk_common.h"
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+
+struct GemmArgs {
+    int M, N, K;
+    double alpha, beta;
+    const double* A; long lda;
+    const double* B; long ldb;
+    double* C; long ldc;
+    int lower_only;
+    int vecA, vecB;
+    int ntm, ntn, ntiles;
+};
+
+// KC = true : operand stored [x][k] (k contiguous);  KC = false : stored [k][x] (x contiguous)
+template <bool KC, int BX>
+__device__ __forceinline__ void load_tile(const double* __restrict__ P, long ld, int x0, int X, int k0, int K, bool vec,
+                                          d2 (&r)[BX * BK / 512]) {
+    const int t = threadIdx.x;
+    // interior tiles (workgroup-uniform test -> scalar branch): unguarded 16-byte loads
+    if (vec && x0 + BX <= X && k0 + BK <= K) {
+#pragma unroll
+        for (int i = 0; i < BX * BK / 512; ++i) {
+            const int lin = t + 256 * i;
+            const double* ptr = KC ? P + (long)(x0 + lin / (BK / 2)) * ld + k0 + (lin % (BK / 2)) * 2
+                                   : P + (long)(k0 + lin / (BX / 2)) * ld + x0 + (lin % (BX / 2)) * 2;
+            r[i] = *reinterpret_cast<const d2*>(ptr);
+        }
+        return;
+    }
+    // edge tiles / unaligned operands: clamped addresses + selects (no divergent branches)
+#pragma unroll
+    for (int i = 0; i < BX * BK / 512; ++i) {
+        const int lin = t + 256 * i;
+        int x, k;
+        if (KC) { x = x0 + lin / (BK / 2); k = k0 + (lin % (BK / 2)) * 2; }
+        else    { k = k0 + lin / (BX / 2); x = x0 + (lin % (BX / 2)) * 2; }
+        const int xc0 = min(x, X - 1), kc0 = min(k, K - 1);
+        const int xc1 = KC ? xc0 : min(x + 1, X - 1), kc1 = KC ? min(k + 1, K - 1) : kc0;
+        const double e0 = KC ? P[(long)xc0 * ld + kc0] : P[(long)kc0 * ld + xc0];
+        const double e1 = KC ? P[(long)xc1 * ld + kc1] : P[(long)kc1 * ld + xc1];
+        const bool v0 = (x < X) && (k < K);
+        const bool v1 = KC ? ((x < X) && (k + 1 < K)) : ((k < K) && (x + 1 < X));
+        r[i].x = v0 ? e0 : 0.0;
+        r[i].y = v1 ? e1 : 0.0;
+    }
+}
+
+template <bool KC, int BX>
+__device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&r)[BX * BK / 512]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < BX * BK / 512; ++i) {
+        const int lin = t + 256 * i;
+        int off;
+        if (KC) off = (lin / (BK / 2)) * (BK + 2) + (lin % (BK / 2)) * 2;
+        else    off = (lin / (BX / 2)) * (BX + 16) + (lin % (BX / 2)) * 2;
+        *reinterpret_cast<d2*>(lds + off) = r[i];
+    }
+}
+
+// element (x, k) of a staged tile
+template <bool KC, int BX>
+__device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, int k) {
+    return KC ? lds[x * (BK + 2) + k] : lds[k * (BX + 16) + x];
+}
+
+__device__ __forceinline__ void map_tile(const GemmArgs& g, int& tm, int& tn) {
+    // XCD-aware bijective remap (cdna_hip_programming.md §5 "XCD swizzle must be bijective")
+    const int nwg = g.ntiles;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (g.lower_only) {
+        int i = (int)((sqrt(8.0 * (double)logical + 1.0) - 1.0) * 0.5);
+        while ((long)(i + 1) * (i + 2) / 2 <= logical) ++i;
+        while ((long)i * (i + 1) / 2 > logical) --i;
+        tm = i; tn = logical - i * (i + 1) / 2;
+    } else {
+        constexpr int GROUP = 8;
+        const int per_group = GROUP * g.ntn;
+        const int gid = logical / per_group;
+        const int first = gid * GROUP;
+        const int gsz = min(g.ntm - first, GROUP);
+        const int rem = logical - gid * per_group;
+        tm = first + rem % gsz;
+        tn = rem / gsz;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    constexpr int A_SZ = TA ? BK * (BM + 16) : BM * (BK + 2);
+    constexpr int B_SZ = TB ? BN * (BK + 2) : BK * (BN + 16);
+    __shared__ __attribute__((aligned(16))) double smem[2 * (A_SZ + B_SZ)];
+    double* const As = smem;
+    double* const Bs = smem + 2 * A_SZ;
+
+    int tm, tn;
+    map_tile(g, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int li = lane & 15, lk = lane >> 4;
+
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    d2 ra[BM * BK / 512], rb[BN * BK / 512];
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile<!TA, BM>(g.A, g.lda, m0, g.M, 0, g.K, g.vecA, ra);
+    load_tile<TB, BN>(g.B, g.ldb, n0, g.N, 0, g.K, g.vecB, rb);
+    store_tile<!TA, BM>(As, ra);
+    store_tile<TB, BN>(Bs, rb);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, g.vecA, ra);
+            load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, g.vecB, rb);
+        }
+        const double* __restrict__ as = As + cur * A_SZ;
+        const double* __restrict__ bs = Bs + cur * B_SZ;
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            double a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = lds_at<!TA, BM>(as, wm0 + 16 * i + li, 4 * ks + lk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = lds_at<TB, BN>(bs, wn0 + 16 * j + li, 4 * ks + lk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_tile<!TA, BM>(As + (cur ^ 1) * A_SZ, ra);
+            store_tile<TB, BN>(Bs + (cur ^ 1) * B_SZ, rb);
+        }
+        __syncthreads();
+    }
+
+    const bool has_beta = (g.beta != 0.0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm0 + 16 * i + lk + 4 * r;
+            if (row >= g.M) continue;
+            double* crow = g.C + (long)row * g.ldc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 16 * j + li;
+                if (col < g.N) {
+                    double v = g.alpha * acc[i][j][r];
+                    if (has_beta) v += g.beta * crow[col];
+                    crow[col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
+    g.ntm = gpk_ceil_div(g.M, BM);
+    g.ntn = gpk_ceil_div(g.N, BN);
+    g.ntiles = g.lower_only ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
+    dim3 grid(g.ntiles), block(256);
+    if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, 0, h->stream>>>(g);
+    else if (!ta && tb) gemm_f64_kernel<BM, BN, WM, WN, false, true><<<grid, block, 0, h->stream>>>(g);
+    else if (ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, true, false><<<grid, block, 0, h->stream>>>(g);
+    else gemm_f64_kernel<BM, BN, WM, WN, true, true><<<grid, block, 0, h->stream>>>(g);
+    GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
+__global__ void symmetrize_kernel(double* A, int n, long lda) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i < n && j < n && j > i) A[(long)i * lda + j] = A[(long)j * lda + i];
+}
+
+__global__ void tril_kernel(double* A, int n, long lda) {
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i < n && j < n && j > i) A[(long)i * lda + j] = 0.0;
+}
+
+}  // namespace
+
+int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only) {
+    if (m <= 0 || n <= 0) return 0;
+    if (k < 0 || !A || !B || !C) return gpk_bad_arg(h, "gemm: sizes/pointers");
+    if (lower_only && m != n) return gpk_bad_arg(h, "gemm: lower_only needs a square C");
+    GemmArgs g;
+    g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.lower_only = lower_only ? 1 : 0;
+    g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
+    g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
+    // big tiles once they fill the chip (256 CUs x 2 resident workgroups); small tiles keep more CUs busy otherwise
+    const long tm = gpk_ceil_div(m, 128), tn = gpk_ceil_div(n, 128);
+    const long big_tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    if (big_tiles >= 384) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
+    return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
+}
+
+extern "C" int gpk_gemm(gpk_handle h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
+                        const double* B, int ldb, double beta, double* C, int ldc) {
+    if (!h) return GPK_ERR_ARG;
+    return gpk_i_gemm(h, ta != 0, tb != 0, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, false);
+}
+
+extern "C" int gpk_symmetrize_lower(gpk_handle h, double* A, int n, int lda) {
+    if (!h || !A) return GPK_ERR_ARG;
+    if (n <= 0) return 0;
+    dim3 grid(gpk_ceil_div(n, 64), gpk_ceil_div(n, 4));
+    symmetrize_kernel<<<grid, 256, 0, h->stream>>>(A, n, lda);
+    GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
+extern "C" int gpk_tril(gpk_handle h, double* A, int n, int lda) {
+    if (!h || !A) return GPK_ERR_ARG;
+    if (n <= 0) return 0;
+    dim3 grid(gpk_ceil_div(n, 64), gpk_ceil_div(n, 4));
+    tril_kernel<<<grid, 256, 0, h->stream>>>(A, n, lda);
+    GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
+extern "C" int gpk_syrk(gpk_handle h, int n, int k, double alpha, const double* A, int lda, double beta, double* C,
+                        int ldc, int full) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_TRY(gpk_i_gemm(h, true, false, n, n, k, alpha, A, lda, A, lda, beta, C, ldc, true));
+    if (full) return gpk_symmetrize_lower(h, C, n, ldc);
+    return 0;
+}

@@ -1,0 +1,238 @@
+// gpk_gn.hip -- device-resident Gauss-Newton step.
+//
+// Reference: *.GN_method / Hessian_GN / grad_loss / loss of src/PDEs.py:82-135,278-343,418-498,137-201 and
+// src/InverseProblems.py:105-186.  There, per step: H = hessian(GN_loss) by forward-over-reverse autodiff through a
+// general LU solve of the triangular L, g = grad(loss) through another LU solve, delta = LU-solve(H, g), and a third
+// LU solve for the new loss.  Here:
+//     S  = [ L^{-1} A(z) | L^{-1} F(z) ]          one blocked TRSM, nz+1 right-hand sides       (N^2 nz flops)
+//     Hb = S^T S = [[H/2, g/2], [g^T/2, loss]]    one SYRK on the MFMA units                    (N nz^2 flops)
+//     chol(Hb) = [[L_H, 0], [y^T, .]], y = L_H^{-1} g/2: the forward solve of POTRS comes free   (nz^3/3 flops)
+//     delta = L_H^{-T} y ;  z <- z - step * delta
+// A(z) is diagonal/identity/zero blocks: it is written straight into the S buffer, never built densely
+// on the host.  Several row groups with their own factor are stacked (Darcy: L_a, L_u, and the data misfit as rows
+// with identity factor; relaxed elliptic: the penalty rows).
+#include "gpk_common.h"
+
+namespace {
+
+struct Group { const double* L; int ldl; int n; int off; };
+
+struct Dims { int nz; int rows; int ngroups; Group g[3]; };
+
+int gn_dims(const gpk_gn_problem* p, Dims& d) {
+    const int Nd = p->Nd, Nb = p->Nb;
+    if (Nd <= 0 || Nb < 0) return GPK_ERR_ARG;
+    switch (p->system) {
+        case GPK_GN_ELLIPTIC:
+            d.nz = Nd; d.ngroups = 1; d.g[0] = {p->L, p->ldl, 2 * Nd + Nb, 0}; d.rows = 2 * Nd + Nb; break;
+        case GPK_GN_BURGERS:
+        case GPK_GN_EIKONAL:
+            d.nz = 3 * Nd; d.ngroups = 1; d.g[0] = {p->L, p->ldl, 4 * Nd + Nb, 0}; d.rows = 4 * Nd + Nb; break;
+        case GPK_GN_DARCY:
+            if (p->Ndata < 0 || p->Ndata > Nd) return GPK_ERR_ARG;
+            d.nz = 6 * Nd; d.ngroups = 3;
+            d.g[0] = {p->L2, p->ldl2, 3 * Nd, 0};
+            d.g[1] = {p->L, p->ldl, 4 * Nd + Nb, 3 * Nd};
+            d.g[2] = {nullptr, 0, p->Ndata, 7 * Nd + Nb};
+            d.rows = 7 * Nd + Nb + p->Ndata; break;
+        case GPK_GN_ELLIPTIC_RELAXED:
+            d.nz = 2 * Nd; d.ngroups = 2;
+            d.g[0] = {p->L, p->ldl, 2 * Nd + Nb, 0};
+            d.g[1] = {nullptr, 0, Nd, 2 * Nd + Nb};
+            d.rows = 3 * Nd + Nb; break;
+        default: return GPK_ERR_ARG;
+    }
+    return 0;
+}
+
+struct BuildArgs {
+    int system, Nd, Nb, Ndata;
+    double p0, p1, lam;
+    const double* f; const double* gb; const double* data; const double* z;
+    double* S; long lds; int fcol; int write_A;
+};
+
+__device__ __forceinline__ void putA(const BuildArgs& a, int r, int c, double v) { if (a.write_A) a.S[(long)r * a.lds + c] = v; }
+__device__ __forceinline__ void putF(const BuildArgs& a, int r, double v) { a.S[(long)r * a.lds + a.fcol] = v; }
+
+// one thread per collocation index: writes the few non-zeros of A(z) and the entries of F(z) it owns
+__global__ __launch_bounds__(256) void gn_build_kernel(BuildArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int Nd = a.Nd, Nb = a.Nb;
+    const double* z = a.z;
+    if (a.system == GPK_GN_ELLIPTIC) {                      // src/PDEs.py:84-85 (F), :95-96 (A)
+        const double alpha = a.p0, m = a.p1;
+        if (t < Nd) {
+            const double zi = z[t];
+            putA(a, t, t, alpha * m * pow(zi, m - 1.0));
+            putA(a, Nd + t, t, 1.0);
+            putF(a, t, alpha * pow(zi, m) - a.f[t]);
+            putF(a, Nd + t, zi);
+        } else if (t < Nd + Nb) putF(a, 2 * Nd + (t - Nd), a.gb[t - Nd]);
+    } else if (a.system == GPK_GN_BURGERS) {                // src/PDEs.py:280-287 (F), :297-305 (A)
+        const double alpha = a.p0, nu = a.p1;
+        if (t < Nd) {
+            const double v0 = z[t], v2 = z[Nd + t], v3 = z[2 * Nd + t];
+            putA(a, t, t, -alpha * v2); putA(a, t, Nd + t, -alpha * v0); putA(a, t, 2 * Nd + t, nu);
+            putA(a, Nd + t, Nd + t, 1.0); putA(a, 2 * Nd + t, 2 * Nd + t, 1.0); putA(a, 3 * Nd + t, t, 1.0);
+            putF(a, t, nu * v3 + a.f[t] - alpha * v0 * v2);
+            putF(a, Nd + t, v2); putF(a, 2 * Nd + t, v3); putF(a, 3 * Nd + t, v0);
+        } else if (t < Nd + Nb) putF(a, 4 * Nd + (t - Nd), a.gb[t - Nd]);
+    } else if (a.system == GPK_GN_EIKONAL) {                // src/PDEs.py:420-428 (F), :441-449 (A)
+        const double eps = a.p0;
+        if (t < Nd) {
+            const double v0 = z[t], v1 = z[Nd + t], v2 = z[2 * Nd + t], ft = a.f[t];
+            putA(a, t, Nd + t, 1.0); putA(a, Nd + t, 2 * Nd + t, 1.0);
+            putA(a, 2 * Nd + t, Nd + t, 2.0 * v1 / eps); putA(a, 2 * Nd + t, 2 * Nd + t, 2.0 * v2 / eps);
+            putA(a, 3 * Nd + t, t, 1.0);
+            putF(a, t, v1); putF(a, Nd + t, v2);
+            putF(a, 2 * Nd + t, -(ft * ft - v1 * v1 - v2 * v2) / eps);
+            putF(a, 3 * Nd + t, v0);
+        } else if (t < Nd + Nb) putF(a, 4 * Nd + (t - Nd), a.gb[t - Nd]);
+    } else if (a.system == GPK_GN_DARCY) {                  // src/InverseProblems.py:106-117 (F), :127-143 (A)
+        const double gam = a.p0;                            // noise_level
+        const int U = 3 * Nd, D = 7 * Nd + Nb;
+        if (t < Nd) {
+            const double w0 = z[t], w1 = z[Nd + t], w2 = z[2 * Nd + t];
+            const double v0 = z[3 * Nd + t], v1 = z[4 * Nd + t], v2 = z[5 * Nd + t];
+            const double fe = a.f[t] * exp(-w0);
+            putA(a, t, Nd + t, 1.0);          putF(a, t, w1);                 // a-part rows [w1; w2; w0]
+            putA(a, Nd + t, 2 * Nd + t, 1.0); putF(a, Nd + t, w2);
+            putA(a, 2 * Nd + t, t, 1.0);      putF(a, 2 * Nd + t, w0);
+            putA(a, U + t, 4 * Nd + t, 1.0);          putF(a, U + t, v1);      // u-part rows [v1; v2; v3; v0; g]
+            putA(a, U + Nd + t, 5 * Nd + t, 1.0);     putF(a, U + Nd + t, v2);
+            putA(a, U + 2 * Nd + t, t, fe);
+            putA(a, U + 2 * Nd + t, Nd + t, -v1);
+            putA(a, U + 2 * Nd + t, 2 * Nd + t, -v2);
+            putA(a, U + 2 * Nd + t, 4 * Nd + t, -w1);
+            putA(a, U + 2 * Nd + t, 5 * Nd + t, -w2);
+            putF(a, U + 2 * Nd + t, -v1 * w1 - v2 * w2 - fe);
+            putA(a, U + 3 * Nd + t, 3 * Nd + t, 1.0); putF(a, U + 3 * Nd + t, v0);
+            if (t < a.Ndata) {                                                  // (1/gamma^2) sum (v0 - data)^2 as rows
+                putA(a, D + t, 3 * Nd + t, 1.0 / gam);
+                putF(a, D + t, (v0 - a.data[t]) / gam);
+            }
+        } else if (t < Nd + Nb) putF(a, U + 4 * Nd + (t - Nd), a.gb[t - Nd]);
+    } else if (a.system == GPK_GN_ELLIPTIC_RELAXED) {       // src/PDEs.py:138-147 (loss), :153-165 (GN_loss)
+        const double alpha = a.p0, m = a.p1, rs = 1.0 / sqrt(a.lam);
+        const int P = 2 * Nd + Nb;
+        if (t < Nd) {
+            const double v = z[t], w = z[Nd + t];
+            putA(a, t, t, 1.0); putF(a, t, v);
+            putA(a, Nd + t, Nd + t, 1.0); putF(a, Nd + t, w);
+            putA(a, P + t, t, -rs); putA(a, P + t, Nd + t, alpha * m * pow(w, m - 1.0) * rs);
+            putF(a, P + t, (-v + alpha * pow(w, m) - a.f[t]) * rs);
+        } else if (t < Nd + Nb) putF(a, 2 * Nd + (t - Nd), a.gb[t - Nd]);
+    }
+}
+
+__global__ void axpy_kernel(int n, double alpha, const double* __restrict__ x, double* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+
+__global__ void scale_kernel(int n, double alpha, double* __restrict__ x) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= alpha;
+}
+
+int build(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, long lds, int fcol, int write_A) {
+    BuildArgs a;
+    a.system = p->system; a.Nd = p->Nd; a.Nb = p->Nb; a.Ndata = p->Ndata;
+    a.p0 = p->p0; a.p1 = p->p1; a.lam = p->pen_lambda;
+    a.f = p->rhs_f; a.gb = p->bdy_g; a.data = p->data_u; a.z = z;
+    a.S = S; a.lds = lds; a.fcol = fcol; a.write_A = write_A;
+    gn_build_kernel<<<gpk_ceil_div(p->Nd + p->Nb, 256), 256, 0, h->stream>>>(a);
+    GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
+int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
+    if (!p) return gpk_bad_arg(h, "gn: null problem");
+    if (gn_dims(p, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
+    if (!p->rhs_f || (p->Nb > 0 && !p->bdy_g) || !p->L) return gpk_bad_arg(h, "gn: null rhs_f/bdy_g/L");
+    if (p->system == GPK_GN_DARCY && (!p->L2 || (p->Ndata > 0 && !p->data_u))) return gpk_bad_arg(h, "gn: Darcy needs L2 and data_u");
+    return 0;
+}
+
+// S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered)
+int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, double* S, int lds,
+                              double* Hb, int ldh, double alpha) {
+    const int nc = d.nz + 1;
+    if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
+    GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
+    GPK_TRY(build(h, p, z, S, lds, d.nz, 1));
+    for (int k = 0; k < d.ngroups; ++k)
+        if (d.g[k].L) GPK_TRY(gpk_i_trsm_left(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
+    GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, S, lds, S, lds, 0.0, Hb, ldh, true));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gpk_gn_dims(const gpk_gn_problem* p, int* nz, int* s_rows) {
+    Dims d;
+    if (!p || gn_dims(p, d) != 0) return GPK_ERR_ARG;
+    if (nz) *nz = d.nz;
+    if (s_rows) *s_rows = d.rows;
+    return 0;
+}
+
+extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, double step_size, double* S, int lds,
+                           double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info) {
+    if (!h || !z || !S || !Hb || !delta) return GPK_ERR_ARG;
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    const int nz = d.nz;
+    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0));
+    double* d_loss = h->d_scalars;
+    GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));                     // last row of the factor = (L_H^{-1} g/2)^T
+    GPK_HIP(h, hipMemcpyAsync(delta, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, delta));
+    axpy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, delta, z);
+    GPK_LAUNCH_CHECK(h);
+    int info = 0;
+    double loss = 0.0;
+    GPK_HIP(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipMemcpyAsync(&loss, d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    if (info == nz + 1) info = 0;          // the border pivot loss - y^T y is not part of H (may round below zero)
+    if (host_info) *host_info = info;
+    if (host_loss_in) *host_loss_in = loss;
+    return 0;
+}
+
+extern "C" int gpk_gn_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double* work, double* host_loss) {
+    if (!h || !z || !work || !host_loss) return GPK_ERR_ARG;
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    GPK_HIP(h, hipMemsetAsync(work, 0, (size_t)d.rows * sizeof(double), h->stream));
+    GPK_TRY(build(h, p, z, work, 1, 0, 0));
+    for (int k = 0; k < d.ngroups; ++k)
+        if (d.g[k].L) GPK_TRY(gpk_i_trsv(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, work + d.g[k].off));
+    GPK_TRY(gpk_i_dot(h, work, work, d.rows, h->d_scalars + 1));
+    GPK_HIP(h, hipMemcpyAsync(host_loss, h->d_scalars + 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, int lds, double* H,
+                                   int ldh, double* g) {
+    if (!h || !z || !S || !H) return GPK_ERR_ARG;
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, H, ldh, 2.0));   // H = 2 S^T S, g = 2 S^T w in the border row
+    if (g) GPK_HIP(h, hipMemcpyAsync(g, H + (long)d.nz * ldh, (size_t)d.nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    return gpk_symmetrize_lower(h, H, d.nz, ldh);
+}
+
+extern "C" int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* p, const double* z, double* out) {
+    if (!h || !z || !out) return GPK_ERR_ARG;
+    Dims d;
+    gpk_gn_problem q = *p;
+    if (gn_dims(&q, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
+    GPK_HIP(h, hipMemsetAsync(out, 0, (size_t)d.rows * sizeof(double), h->stream));
+    return build(h, &q, z, out, 1, 0, 0);
+}

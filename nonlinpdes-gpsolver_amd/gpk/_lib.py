@@ -1,0 +1,91 @@
+"""Loader and prototypes for libgpk.so.  Every symbol declared in include/gpk.h is bound here."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libgpk.so')
+
+
+class GpkError(RuntimeError):
+    pass
+
+
+class GNProblemStruct(C.Structure):
+    _fields_ = [('system', C.c_int), ('Nd', C.c_int), ('Nb', C.c_int), ('Ndata', C.c_int),
+                ('p0', C.c_double), ('p1', C.c_double), ('pen_lambda', C.c_double),
+                ('rhs_f', C.c_void_p), ('bdy_g', C.c_void_p), ('data_u', C.c_void_p),
+                ('L', C.c_void_p), ('ldl', C.c_int), ('L2', C.c_void_p), ('ldl2', C.c_int)]
+
+
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_pi, _pd, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_void_p)
+_pp = C.POINTER(GNProblemStruct)
+
+# name -> (restype, argtypes); one entry per function of include/gpk.h
+PROTOTYPES = {
+    'gpk_create': (_i, [_i, _pvp]),
+    'gpk_destroy': (_i, [_vp]),
+    'gpk_last_error': (C.c_char_p, [_vp]),
+    'gpk_version': (C.c_char_p, []),
+    'gpk_set_stream': (_i, [_vp, _vp]),
+    'gpk_synchronize': (_i, [_vp]),
+    'gpk_device_info': (_i, [_vp, C.c_char_p, _i, _pi, C.POINTER(_sz), _pi]),
+    'gpk_malloc': (_i, [_vp, _sz, _pvp]),
+    'gpk_free': (_i, [_vp, _vp]),
+    'gpk_memset': (_i, [_vp, _vp, _i, _sz]),
+    'gpk_memcpy_h2d': (_i, [_vp, _vp, _vp, _sz]),
+    'gpk_memcpy_d2h': (_i, [_vp, _vp, _vp, _sz]),
+    'gpk_memcpy_d2d': (_i, [_vp, _vp, _vp, _sz]),
+    'gpk_memcpy2d_h2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'gpk_memcpy2d_d2h': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'gpk_memcpy2d_d2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
+    'gpk_timer_start': (_i, [_vp]),
+    'gpk_timer_stop': (_i, [_vp, _pd]),
+    'gpk_assemble': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _d, _i, _vp, _i, _pd]),
+    'gpk_assemble_test': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _i]),
+    'gpk_extend': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    'gpk_potrf': (_i, [_vp, _vp, _i, _i, _pi]),
+    'gpk_tril': (_i, [_vp, _vp, _i, _i]),
+    'gpk_symmetrize_lower': (_i, [_vp, _vp, _i, _i]),
+    'gpk_trsm': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
+    'gpk_potrs': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
+    'gpk_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i]),
+    'gpk_syrk': (_i, [_vp, _i, _i, _d, _vp, _i, _d, _vp, _i, _i]),
+    'gpk_gn_dims': (_i, [_pp, _pi, _pi]),
+    'gpk_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _i, _vp, _pd, _pi]),
+    'gpk_gn_loss': (_i, [_vp, _pp, _vp, _vp, _pd]),
+    'gpk_gn_hessian_grad': (_i, [_vp, _pp, _vp, _vp, _i, _vp, _i, _vp]),
+    'gpk_gn_measurement': (_i, [_vp, _pp, _vp, _vp]),
+    'gpk_ubench_mfma_f64': (_i, [_vp, _i, _pd]),
+    'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
+}
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def declared_symbols():
+    return sorted(PROTOTYPES)
+
+
+def load_library():
+    """dlopen libgpk.so and attach prototypes.  Raises GpkError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise GpkError(f'{_LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                       '(hipcc --offload-arch=gfx950); there is no CPU fallback')
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:
+        raise GpkError(f'cannot load {_LIB_PATH}: {e}') from e
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,276 @@
+"""Thin object layer over the C ABI: a context (handle + stream), device arrays with a padded leading dimension,
+and the calls of include/gpk.h with numpy-friendly signatures."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import GNProblemStruct, GpkError, load_library
+
+LAYOUT = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_u': 2, 'Darcy_a': 3}
+KERNEL = {'Gaussian': 0, 'anisotropic_Gaussian': 1}
+NUGGET = {'none': 0, 'identity': 1, 'adaptive': 2}
+SYSTEM = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_flow2d': 3, 'Nonlinear_elliptic_relaxed': 4}
+
+
+def pad_ld(n, mult=16):
+    """Leading dimension in elements: multiple of 16 doubles (128 B) so rows start on cache-line boundaries and the
+    GEMM's 16-byte loads apply to every sub-block the recursion produces."""
+    return ((int(n) + mult - 1) // mult) * mult
+
+
+def kernel_params(kernel, kernel_parameter):
+    if kernel == 'Gaussian':
+        return (C.c_double * 2)(float(kernel_parameter), 0.0)
+    if kernel == 'anisotropic_Gaussian':
+        return (C.c_double * 2)(float(kernel_parameter[0]), float(kernel_parameter[1]))
+    raise ValueError(f'unknown kernel {kernel!r}')
+
+
+class DeviceArray:
+    """Row-major float64 device buffer, (rows, cols) with leading dimension ld >= cols (vectors: cols == ld == 1)."""
+
+    def __init__(self, ctx, rows, cols=1, ld=None, zero=False):
+        self.ctx = ctx
+        self.rows, self.cols = int(rows), int(cols)
+        self.ld = int(ld) if ld is not None else (1 if self.cols == 1 else pad_ld(self.cols))
+        self.nbytes = max(self.rows, 1) * self.ld * 8
+        p = C.c_void_p()
+        ctx._chk(ctx.lib.gpk_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        if zero:
+            self.zero()
+
+    def zero(self):
+        self.ctx._chk(self.ctx.lib.gpk_memset(self.ctx.h, self.ptr, 0, self.nbytes))
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        a2 = a.reshape(self.rows, self.cols)
+        self.ctx._chk(self.ctx.lib.gpk_memcpy2d_h2d(self.ctx.h, self.ptr, self.ld * 8, a2.ctypes.data, self.cols * 8,
+                                                    self.cols * 8, self.rows))
+        return self
+
+    def download(self, rows=None, cols=None, row0=0, col0=0):
+        rows = self.rows - row0 if rows is None else rows
+        cols = self.cols - col0 if cols is None else cols
+        out = np.empty((rows, cols), dtype=np.float64)
+        if rows and cols:
+            src = self.ptr + (row0 * self.ld + col0) * 8
+            self.ctx._chk(self.ctx.lib.gpk_memcpy2d_d2h(self.ctx.h, out.ctypes.data, cols * 8, src, self.ld * 8, cols * 8, rows))
+        return out[:, 0] if (self.cols == 1 and cols == 1) else out
+
+    def at(self, row=0, col=0):
+        return self.ptr + (row * self.ld + col) * 8
+
+    def free(self):
+        if getattr(self, 'ptr', None):
+            self.ctx.lib.gpk_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GNProblem:
+    """Device-side description of one equation's Gauss-Newton system (gpk_gn_problem)."""
+
+    def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None):
+        self.ctx = ctx
+        self.keep = []
+        def dev(v):
+            v = np.asarray(v, dtype=np.float64).ravel()
+            d = DeviceArray(ctx, max(v.size, 1)).upload(v) if v.size else DeviceArray(ctx, 1)
+            self.keep.append(d)
+            return d
+        self.rhs_f, self.bdy_g = dev(rhs_f), dev(bdy_g)
+        self.data_u = dev(data_u) if data_u is not None else None
+        self.L, self.L2 = L, L2
+        s = GNProblemStruct()
+        s.system = SYSTEM[system] if isinstance(system, str) else int(system)
+        s.Nd, s.Nb = int(Nd), int(Nb)
+        s.Ndata = 0 if data_u is None else int(np.asarray(data_u).size)
+        s.p0, s.p1, s.pen_lambda = float(p0), float(p1), float(pen_lambda)
+        s.rhs_f, s.bdy_g = self.rhs_f.ptr, self.bdy_g.ptr
+        s.data_u = self.data_u.ptr if self.data_u is not None else None
+        s.L, s.ldl = L.ptr, L.ld
+        s.L2, s.ldl2 = (L2.ptr, L2.ld) if L2 is not None else (None, 0)
+        self.struct = s
+        nz, rows = C.c_int(), C.c_int()
+        ctx._chk(ctx.lib.gpk_gn_dims(C.byref(s), C.byref(nz), C.byref(rows)))
+        self.nz, self.rows = nz.value, rows.value
+        self._S = self._H = self._delta = self._work = None
+
+    def workspace(self):
+        if self._S is None:
+            ld = pad_ld(self.nz + 1)
+            self._S = DeviceArray(self.ctx, self.rows, self.nz + 1, ld)
+            self._H = DeviceArray(self.ctx, self.nz + 1, self.nz + 1, ld)
+            self._delta = DeviceArray(self.ctx, self.nz)
+            self._work = DeviceArray(self.ctx, self.rows)
+        return self._S, self._H, self._delta, self._work
+
+    def release_workspace(self):
+        for a in (self._S, self._H, self._delta, self._work):
+            if a is not None:
+                a.free()
+        self._S = self._H = self._delta = self._work = None
+
+
+class Context:
+    """One handle = one device + one stream.  Raises GpkError if the library or the device is missing."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.gpk_create(int(device), C.byref(h))
+        if rc != 0:
+            raise GpkError(f'gpk_create(device={device}) failed with {rc}: no usable gfx950 device '
+                           '(this library has no CPU fallback)')
+        self.h = h
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise GpkError(f'libgpk error {rc}: {self.lib.gpk_last_error(self.h).decode()}')
+        return rc
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.gpk_destroy(self.h)
+            self.h = None
+
+    def synchronize(self):
+        self._chk(self.lib.gpk_synchronize(self.h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus, clk, hbm = C.c_int(), C.c_int(), C.c_size_t()
+        self._chk(self.lib.gpk_device_info(self.h, name, 256, C.byref(cus), C.byref(hbm), C.byref(clk)))
+        return dict(name=name.value.decode(), compute_units=cus.value, hbm_bytes=hbm.value, clock_khz=clk.value)
+
+    # ---- arrays ----
+    def empty(self, rows, cols=1, ld=None):
+        return DeviceArray(self, rows, cols, ld)
+
+    def array(self, a):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 1:
+            return DeviceArray(self, a.size).upload(a)
+        return DeviceArray(self, a.shape[0], a.shape[1]).upload(a)
+
+    def timer_start(self):
+        self._chk(self.lib.gpk_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        self._chk(self.lib.gpk_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- assembly ----
+    def assemble(self, layout, kernel, kernel_parameter, Xd, Xb, nugget=0.0, nugget_type='none', out=None):
+        Xd = np.ascontiguousarray(Xd, dtype=np.float64); Xb = np.ascontiguousarray(Xb, dtype=np.float64).reshape(-1, 2)
+        Nd, Nb = Xd.shape[0], Xb.shape[0]
+        lay = LAYOUT[layout]
+        N = {0: 2 * Nd + Nb, 1: 4 * Nd + Nb, 2: 4 * Nd + Nb, 3: 3 * Nd}[lay]
+        dXd = self.array(Xd); dXb = self.array(Xb) if Nb else DeviceArray(self, 1, 2)
+        T = out if out is not None else DeviceArray(self, N, N)
+        ratios = (C.c_double * 3)()
+        self._chk(self.lib.gpk_assemble(self.h, lay, KERNEL[kernel], kernel_params(kernel, kernel_parameter),
+                                        dXd.ptr, Nd, dXb.ptr, Nb, float(nugget), NUGGET[nugget_type], T.ptr, T.ld, ratios))
+        self.synchronize()
+        return T, list(ratios)
+
+    def assemble_test(self, layout, kernel, kernel_parameter, Xt, Xd, Xb):
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64); Xd = np.ascontiguousarray(Xd, dtype=np.float64)
+        Xb = np.ascontiguousarray(Xb, dtype=np.float64).reshape(-1, 2)
+        Nt, Nd, Nb = Xt.shape[0], Xd.shape[0], Xb.shape[0]
+        lay = LAYOUT[layout]
+        N = {0: 2 * Nd + Nb, 1: 4 * Nd + Nb, 2: 4 * Nd + Nb, 3: 3 * Nd}[lay]
+        dXt, dXd = self.array(Xt), self.array(Xd)
+        dXb = self.array(Xb) if Nb else DeviceArray(self, 1, 2)
+        out = DeviceArray(self, Nt, N)
+        self._chk(self.lib.gpk_assemble_test(self.h, lay, KERNEL[kernel], kernel_params(kernel, kernel_parameter),
+                                             dXt.ptr, Nt, dXd.ptr, Nd, dXb.ptr, Nb, out.ptr, out.ld))
+        self.synchronize()
+        return out
+
+    def extend(self, layout, kernel, kernel_parameter, Xt, Xd, Xb, coeff):
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64); Xd = np.ascontiguousarray(Xd, dtype=np.float64)
+        Xb = np.ascontiguousarray(Xb, dtype=np.float64).reshape(-1, 2)
+        Nt, Nd, Nb = Xt.shape[0], Xd.shape[0], Xb.shape[0]
+        dXt, dXd = self.array(Xt), self.array(Xd)
+        dXb = self.array(Xb) if Nb else DeviceArray(self, 1, 2)
+        dc = coeff if isinstance(coeff, DeviceArray) else self.array(coeff)
+        out = DeviceArray(self, Nt)
+        self._chk(self.lib.gpk_extend(self.h, LAYOUT[layout], KERNEL[kernel], kernel_params(kernel, kernel_parameter),
+                                      dXt.ptr, Nt, dXd.ptr, Nd, dXb.ptr, Nb, dc.ptr, out.ptr))
+        self.synchronize()
+        return out
+
+    # ---- dense ----
+    def potrf(self, A, n=None):
+        n = A.rows if n is None else n
+        info = C.c_int()
+        self._chk(self.lib.gpk_potrf(self.h, A.ptr, n, A.ld, C.byref(info)))
+        return info.value
+
+    def tril(self, A, n=None):
+        self._chk(self.lib.gpk_tril(self.h, A.ptr, A.rows if n is None else n, A.ld))
+
+    def symmetrize(self, A, n=None):
+        self._chk(self.lib.gpk_symmetrize_lower(self.h, A.ptr, A.rows if n is None else n, A.ld))
+
+    def trsm(self, L, B, trans=False, n=None, nrhs=None):
+        n = L.rows if n is None else n
+        nrhs = B.cols if nrhs is None else nrhs
+        self._chk(self.lib.gpk_trsm(self.h, int(trans), L.ptr, n, L.ld, B.ptr, nrhs, B.ld))
+
+    def potrs(self, L, B, n=None, nrhs=None):
+        n = L.rows if n is None else n
+        nrhs = B.cols if nrhs is None else nrhs
+        self._chk(self.lib.gpk_potrs(self.h, L.ptr, n, L.ld, B.ptr, nrhs, B.ld))
+
+    def gemm(self, ta, tb, m, n, k, alpha, A, B, beta, Cm):
+        self._chk(self.lib.gpk_gemm(self.h, int(ta), int(tb), m, n, k, float(alpha), A.ptr, A.ld, B.ptr, B.ld, float(beta), Cm.ptr, Cm.ld))
+
+    def syrk(self, n, k, alpha, A, beta, Cm, full=False):
+        self._chk(self.lib.gpk_syrk(self.h, n, k, float(alpha), A.ptr, A.ld, float(beta), Cm.ptr, Cm.ld, int(full)))
+
+    # ---- Gauss-Newton ----
+    def gn_step(self, prob, z, step_size=1.0):
+        S, H, delta, _ = prob.workspace()
+        loss, info = C.c_double(), C.c_int()
+        self._chk(self.lib.gpk_gn_step(self.h, C.byref(prob.struct), z.ptr, float(step_size), S.ptr, S.ld, H.ptr, H.ld,
+                                       delta.ptr, C.byref(loss), C.byref(info)))
+        return loss.value, info.value
+
+    def gn_loss(self, prob, z):
+        _, _, _, work = prob.workspace()
+        loss = C.c_double()
+        self._chk(self.lib.gpk_gn_loss(self.h, C.byref(prob.struct), z.ptr, work.ptr, C.byref(loss)))
+        return loss.value
+
+    def gn_hessian_grad(self, prob, z):
+        S, H, delta, _ = prob.workspace()
+        self._chk(self.lib.gpk_gn_hessian_grad(self.h, C.byref(prob.struct), z.ptr, S.ptr, S.ld, H.ptr, H.ld, delta.ptr))
+        self.synchronize()
+        return H.download(prob.nz, prob.nz), delta.download()
+
+    def gn_measurement(self, prob, z):
+        _, _, _, work = prob.workspace()
+        self._chk(self.lib.gpk_gn_measurement(self.h, C.byref(prob.struct), z.ptr, work.ptr))
+        self.synchronize()
+        return work.download()
+
+    # ---- micro-benchmarks ----
+    def ubench_mfma_f64(self, iters=20000):
+        v = C.c_double()
+        self._chk(self.lib.gpk_ubench_mfma_f64(self.h, iters, C.byref(v)))
+        return v.value
+
+    def ubench_hbm_write(self, nbytes=1 << 30, iters=10):
+        v = C.c_double()
+        self._chk(self.lib.gpk_ubench_hbm_write(self.h, nbytes, iters, C.byref(v)))
+        return v.value
