@@ -125,6 +125,12 @@ int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* host_prob, const dou
 /* measurement vector(s) F(z) = sol_vec (src/PDEs.py:132-134,338-342,488-497; IP.py:176-186): out (s_rows,) */
 int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* out);
 
+/* development aids (process-wide): key 0 = force the GEMM tile configuration (0 auto, 1 = 128x128, 2 = 64x64);
+ * key 2 = run multi-RHS triangular solves as 4 column groups on concurrent streams (0 off, default) */
+int gpk_debug_set(int key, int value);
+/* development aid: enable/disable and read the shader-clock phase stamps of the 64-wide diagonal-block kernels */
+int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable);
+
 /* ---- micro-benchmarks used to fix the roofline denominators ------------------------------------------------ */
 int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops);      /* v_mfma_f64_16x16x4_f64 issue rate */
 int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, double* host_gbps);

@@ -20,6 +20,8 @@ struct gpk_ctx {
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // column-group streams of the multi-RHS triangular solve
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     std::string err;
 };
 
@@ -44,6 +46,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
                const double* B, int ldb, double beta, double* C, int ldc, bool lower_only);
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+// same, right-hand sides split into independent column groups that run on concurrent streams
+int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);
 int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x);   // x contiguous
 int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_out);    // d_out device scalar

@@ -42,14 +42,19 @@ extern "C" int gpk_create(int device, gpk_handle* out) {
 
 extern "C" int gpk_destroy(gpk_handle h) {
     if (!h) return 0;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    if (h->d_info) hipFree(h->d_info);
-    if (h->d_scalars) hipFree(h->d_scalars);
-    if (h->d_pts) hipFree(h->d_pts);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->d_info) (void)hipFree(h->d_info);
+    if (h->d_scalars) (void)hipFree(h->d_scalars);
+    if (h->d_pts) (void)hipFree(h->d_pts);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < 3; ++i) {
+        if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
 }

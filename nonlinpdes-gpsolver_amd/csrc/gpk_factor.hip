@@ -7,7 +7,7 @@
 //
 // Structure: all O(n^3) work is delegated to gpk_i_gemm (MFMA); only 64-wide diagonal blocks are handled by the
 // substitution kernels below (true substitution, no explicit inverses: cond(Theta) ~ 1e13+ leaves no slack).
-//   potrf(A)      = potrf(A11); A21 <- A21 L11^{-T}; A22 -= A21 A21^T (lower tiles only); potrf(A22)
+//   potrf(A)      = two-level right-looking (see gpk_i_potrf)
 //   trsm_left(L)  = solve with L11; B2 -= L21 X1; solve with L22          (transposed: mirror image)
 //   trsm_right_lt = X1 <- X1 L11^{-T}; X2 -= X1 L21^T; X2 <- X2 L22^{-T}
 // The recursion splits at multiples of 64/128 so that sub-blocks stay 16-byte aligned for the GEMM's vector loads.
@@ -19,125 +19,201 @@ constexpr int NB = 64;
 
 __device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
-// ---- 64x64 (or smaller) Cholesky by ONE wave: lane i owns row i in registers ---------------------------------
-__global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base) {
-    __shared__ double tile[NB * (NB + 1)];
-    __shared__ double col[NB];
-    const int lane = threadIdx.x;
-    for (int r = 0; r < NB; ++r) {                                   // coalesced rows -> LDS (identity padding)
-        double v = (r == lane) ? 1.0 : 0.0;
-        if (r < n && lane < n) v = A[(long)r * lda + lane];
-        tile[r * (NB + 1) + lane] = v;
-    }
-    __syncthreads();
-    double a[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) a[j] = tile[lane * (NB + 1) + j];
-    int bad = 0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const double d = bcast(a[j], j);                             // pivot a_jj lives in lane j
-        if (!(d > 0.0) && bad == 0) bad = j + 1;                     // NaN-safe test; wave-uniform
-        const double s = sqrt(d);
-        const double lij = (lane == j) ? s : a[j] / s;
-        a[j] = lij;
-        col[lane] = lij;
-        __syncthreads();
-#pragma unroll
-        for (int k = j + 1; k < NB; ++k) a[k] -= lij * col[k];       // rank-1 update of row `lane`
-        __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) tile[lane * (NB + 1) + j] = a[j];
-    __syncthreads();
-    for (int r = 0; r < n; ++r)
-        if (lane <= r) A[(long)r * lda + lane] = tile[r * (NB + 1) + lane];
-    if (bad && bad <= n && lane == 0) atomicCAS(info, 0, pivot_base + bad);
+// broadcast from a COMPILE-TIME lane through the scalar unit (2 x v_readlane_b32): no LDS, no VGPRs, no barrier
+__device__ __forceinline__ double bcast_const(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
 }
 
-// ---- substitution with a <=64-wide diagonal block, one RHS column (or row) per lane ---------------------------
-// TRANS=false: L X = B;  TRANS=true: L^T X = B.
-// ROWVEC=false: element (j, c) of B at B[j*ldb + c]  (left solve: lanes = consecutive columns, coalesced)
-// ROWVEC=true : element (j, c) of B at B[c*ldb + j]  (right solve X L^T = A viewed as L X^T = A^T; rows of X are
-//               staged through LDS so that global traffic stays coalesced)
+// t[r] = P[r*ld + lane] for r < 64, all loads independent (clamped addresses, no branches): one latency, not 64
+__device__ __forceinline__ void load_rows(const double* __restrict__ P, long ld, int nrows, int ncols, int lane, double (&t)[NB]) {
+    const int cl = min(lane, ncols - 1);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) t[r] = P[(long)min(r, nrows - 1) * ld + cl];
+}
+
+// ---- 64x64 (or smaller) Cholesky by ONE wave, compact loops ---------------------------------------------------
+// The block lives in LDS; it is factored in four panels of 16 columns.  Lane r owns row r: the 16 panel entries of
+// its row sit in registers while the panel is factored right-looking (pivot and multipliers are broadcast with
+// v_readlane from the lane that owns them), then the trailing columns are updated from LDS in a loop whose body is
+// 16 FMAs fed by broadcast ds_read_b128.  Straight-line unrolling of the whole 64x64 factorisation (30+ KB of code
+// executed once by one wave) ran 4x slower than this: it is bound by instruction fetch, not by arithmetic.
+// development aid: phase time stamps (shader clock) of workgroup 0, enabled by gpk_debug_set(1, 1)
+__device__ unsigned long long gpk_dbg_stamps[16];
+#define GPK_STAMP(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
+
+constexpr int RB = 16;          // register block
+constexpr int LB = 32;          // global loads kept in flight per staging round trip (a round trip costs ~1 us)
+constexpr int XS = NB + 1;      // odd stride: lane-per-row / lane-per-column accesses hit 64 distinct banks
+constexpr int WS = NB + 2;      // even stride: 16-byte aligned broadcast reads of 16 consecutive coefficients
+
+__device__ __forceinline__ double bcast_lane(double v, int src_lane /* wave-uniform */) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base, int dbg) {
+    GPK_STAMP(0);
+    __shared__ double As[NB * XS];                                  // As[r*XS + c]
+    __shared__ __attribute__((aligned(16))) double Ps[NB * RB];     // factored panel, Ps[r*16 + i] = L[r][r0+i]
+    const int lane = threadIdx.x;
+    const int cl = min(lane, n - 1);
+    {                                                               // coalesced rows, all 64 loads in flight at once
+        double t[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) t[u] = A[(long)min(u, n - 1) * lda + cl];
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            As[u * XS + lane] = (u < n && lane < n) ? t[u] : ((u == lane) ? 1.0 : 0.0);   // identity padding
+    }
+    __syncthreads();
+    GPK_STAMP(1);
+    int bad = 0;
+    const int nblk = (n + RB - 1) / RB;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int r0 = kb * RB;
+        double a[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) a[i] = As[lane * XS + r0 + i];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const double d = bcast_lane(a[j], r0 + j);               // pivot lives in lane r0+j
+            if (!(d > 0.0) && bad == 0) bad = r0 + j + 1;            // NaN-safe, wave-uniform
+            const double rs = rsqrt(d);                              // 1/sqrt(d), then one Newton step for sqrt(d)
+            const double s0 = d * rs;
+            const double sq = fma(fma(-s0, s0, d), 0.5 * rs, s0);
+            const double lij = (lane == r0 + j) ? sq : a[j] * rs;    // LAPACK dpotf2 also scales by the reciprocal
+            a[j] = lij;
+#pragma unroll
+            for (int k = j + 1; k < RB; ++k) a[k] -= lij * bcast_lane(lij, r0 + k);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) { As[lane * XS + r0 + i] = a[i]; Ps[lane * RB + i] = a[i]; }
+        __syncthreads();
+        for (int c = r0 + RB; c < NB; c += 4) {                      // trailing update of row `lane`, 4 columns at a
+            const double* __restrict__ pc = Ps + c * RB;             // time: a single wave needs the ILP (a serial
+            double acc0 = As[lane * XS + c], acc1 = As[lane * XS + c + 1];   // 16-FMA chain costs ~10 cycles per link)
+            double acc2 = As[lane * XS + c + 2], acc3 = As[lane * XS + c + 3];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                acc0 = fma(-a[i], pc[i], acc0);
+                acc1 = fma(-a[i], pc[RB + i], acc1);
+                acc2 = fma(-a[i], pc[2 * RB + i], acc2);
+                acc3 = fma(-a[i], pc[3 * RB + i], acc3);
+            }
+            As[lane * XS + c] = acc0; As[lane * XS + c + 1] = acc1;
+            As[lane * XS + c + 2] = acc2; As[lane * XS + c + 3] = acc3;
+        }
+        __syncthreads();
+    }
+    GPK_STAMP(2);
+#pragma unroll 8
+    for (int r = 0; r < n; ++r)
+        if (lane <= r) A[(long)r * lda + lane] = As[r * XS + lane];
+    if (bad && bad <= n && lane == 0) atomicCAS(info, 0, pivot_base + bad);
+    GPK_STAMP(3);
+}
+
+// ---- substitution with a <=64-wide diagonal block, one RHS column (or row of X) per lane ----------------------
+// TRANS=false: L X = B;  TRANS=true: L^T X = B (index-reversed at load/store so the SAME forward algorithm runs).
+// ROWVEC=false: element (j, c) of B at B[j*ldb + c]  (left solve: lanes = consecutive columns, coalesced rows)
+// ROWVEC=true : element (j, c) of B at B[c*ldb + j]  (right solve X L^T = A viewed as L X^T = A^T; transposed via LDS)
+// X stays in LDS; 16 equations at a time are pulled into registers, solved against their 16x16 diagonal block, and
+// applied to the remaining equations in a loop (16 FMAs per iteration, coefficients by broadcast ds_read_b128).
 template <bool TRANS, bool ROWVEC>
 __global__ __launch_bounds__(64) void trsm_base_kernel(const double* __restrict__ L, long ldl, int nb,
-                                                       double* __restrict__ B, long ldb, int ncols) {
-    constexpr int WS = NB + 2;
-    __shared__ __attribute__((aligned(16))) double W[NB * WS];      // W[i][j] = coefficient of x_i in equation j
-    __shared__ double dg[NB];
-    __shared__ double T[ROWVEC ? NB * (NB + 1) : 1];
+                                                       double* __restrict__ B, long ldb, int ncols, int dbg) {
+    GPK_STAMP(4);
+    __shared__ __attribute__((aligned(16))) double Ws[NB * WS];      // Ws[a*WS + b]: coefficient of x_b in equation a
+    __shared__ double Xs[NB * XS];                                   // Xs[a*XS + lane]
+    __shared__ double rds[NB];                                       // 1 / diagonal
     const int lane = threadIdx.x;
     const int c0 = blockIdx.x * NB;
-    for (int r = 0; r < NB; ++r) {
-        double v = 0.0;
-        if (r < nb && lane < nb) v = L[(long)r * ldl + lane];
-        if (r == lane) dg[r] = (r < nb) ? v : 1.0;
-        if (TRANS) W[r * WS + lane] = (lane < r) ? v : 0.0;          // x_r enters equation `lane` (< r) with L[r][lane]
-        else       W[lane * WS + r] = (lane < r) ? v : 0.0;          // x_lane enters equation r (> lane) with L[r][lane]
-    }
-    double x[NB];
     const int c = c0 + lane;
-    if (ROWVEC) {
-        for (int r = 0; r < NB; ++r) {
-            double v = 0.0;
-            if (c0 + r < ncols && lane < nb) v = B[(long)(c0 + r) * ldb + lane];
-            T[r * (NB + 1) + lane] = v;
+    const int lc = min(lane, nb - 1);
+    const int rl = TRANS ? nb - 1 - lane : lane;                     // mapped index of `lane` (valid when lane < nb)
+    const int nr = ROWVEC ? min(NB, ncols - c0) : nb;                // rows of the B tile as stored in memory
+    const int cc = min(c, ncols - 1);
+    // Two round trips to memory in total (a dependent global load costs ~3 us here: the operands were just written by
+    // another XCD): each half issues 32 rows of L and 32 rows of B together, the LDS zero-fill hides under the first.
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int r0 = half * LB;
+        double tl[LB], tx[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) tl[u] = L[(long)min(r0 + u, nb - 1) * ldl + lc];
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            tx[u] = ROWVEC ? B[(long)(c0 + min(r0 + u, nr - 1)) * ldb + lc] : B[(long)min(r0 + u, nb - 1) * ldb + cc];
+        if (half == 0) {
+            for (int a = 0; a < NB; ++a) { Ws[a * WS + lane] = 0.0; Xs[a * XS + lane] = 0.0; }
+            if (lane < WS - NB) for (int a = 0; a < NB; ++a) Ws[a * WS + NB + lane] = 0.0;
+            rds[lane] = 1.0;
+            __syncthreads();
+            GPK_STAMP(5);
         }
-        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < NB; ++j) x[j] = T[lane * (NB + 1) + j];
-    } else {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {                               // clamped address + select: no divergent branches
-            const double v = B[(long)min(j, nb - 1) * ldb + min(c, ncols - 1)];
-            x[j] = (j < nb) ? v : 0.0;
-        }
-    }
-    const double* Wv = W;
-    if (!TRANS) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const double xi = x[i] / dg[i];
-            x[i] = xi;
-#pragma unroll
-            for (int j = i + 1; j < NB; ++j) x[j] -= Wv[i * WS + j] * xi;
-            __builtin_amdgcn_sched_barrier(0);                       // keep the LDS reads of step i+1 behind step i
-        }
-    } else {
-#pragma unroll
-        for (int i = NB - 1; i >= 0; --i) {
-            const double xi = x[i] / dg[i];
-            x[i] = xi;
-#pragma unroll
-            for (int j = 0; j < i; ++j) x[j] -= Wv[i * WS + j] * xi;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (ROWVEC) {
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NB; ++j) T[lane * (NB + 1) + j] = x[j];
-        __syncthreads();
-        for (int r = 0; r < NB; ++r)
-            if (c0 + r < ncols && lane < nb) B[(long)(c0 + r) * ldb + lane] = T[r * (NB + 1) + lane];
-    } else {
-        // Lanes past the last column redo column ncols-1 and store identical bits (benign): NO conditional block around
-        // the stores -- with one, LLVM sinks the whole FMA chain into it, behind every coefficient load, and spills.
-        double* out = B + min(c, ncols - 1);
-        if (nb == NB) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) out[(long)j * ldb] = x[j];
-        } else {
-            for (int j = 0; j < nb; ++j) {
-                double v = x[0];
-#pragma unroll
-                for (int k = 1; k < NB; ++k) v = (k == j) ? x[k] : v;        // static register indexing
-                out[(long)j * ldb] = v;
+        for (int u = 0; u < LB; ++u) {
+            const int r = r0 + u;
+            if (r < nb && lane < nb) {
+                const int rr = TRANS ? nb - 1 - r : r;
+                // L[r][lane], lane < r: forward -> x_lane in equation r; transposed -> x_r in equation lane
+                if (lane < r) { if (TRANS) Ws[rl * WS + rr] = tl[u]; else Ws[rr * WS + rl] = tl[u]; }
+                if (lane == r) rds[rr] = 1.0 / tl[u];
             }
+            if (ROWVEC) { if (r < nr && lane < nb) Xs[rl * XS + r] = tx[u]; }
+            else        { if (r < nb) Xs[(TRANS ? nb - 1 - r : r) * XS + lane] = tx[u]; }
+        }
+        if (half == 0) GPK_STAMP(6);
+    }
+    __syncthreads();
+    GPK_STAMP(7);
+    const int nblk = (nb + RB - 1) / RB;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int r0 = kb * RB;
+        double x[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) x[i] = Xs[(r0 + i) * XS + lane];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {                               // 16x16 diagonal block, right-looking: the
+            const double xi = x[i] * rds[r0 + i];                    // updates of one step are independent FMAs
+            x[i] = xi;
+#pragma unroll
+            for (int j = i + 1; j < RB; ++j) x[j] = fma(-Ws[(r0 + j) * WS + r0 + i], xi, x[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) Xs[(r0 + i) * XS + lane] = x[i];
+        for (int r = r0 + RB; r < NB; r += 4) {                      // apply to the remaining equations, 4 at a time
+            const double* __restrict__ wr = Ws + r * WS + r0;
+            double acc0 = Xs[r * XS + lane], acc1 = Xs[(r + 1) * XS + lane];
+            double acc2 = Xs[(r + 2) * XS + lane], acc3 = Xs[(r + 3) * XS + lane];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                acc0 = fma(-wr[i], x[i], acc0);
+                acc1 = fma(-wr[WS + i], x[i], acc1);
+                acc2 = fma(-wr[2 * WS + i], x[i], acc2);
+                acc3 = fma(-wr[3 * WS + i], x[i], acc3);
+            }
+            Xs[r * XS + lane] = acc0; Xs[(r + 1) * XS + lane] = acc1;
+            Xs[(r + 2) * XS + lane] = acc2; Xs[(r + 3) * XS + lane] = acc3;
         }
     }
+    __syncthreads();
+    GPK_STAMP(8);
+    if (ROWVEC) {
+        if (lane < nb) {
+#pragma unroll 8
+            for (int r = 0; r < nr; ++r) B[(long)(c0 + r) * ldb + lane] = Xs[rl * XS + r];
+        }
+    } else {
+        if (c < ncols) {
+#pragma unroll 8
+            for (int r = 0; r < nb; ++r) B[(long)r * ldb + c] = Xs[(TRANS ? nb - 1 - r : r) * XS + lane];
+        }
+    }
+    GPK_STAMP(9);
 }
 
 // ---- single-vector triangular solve: 64-wide diagonal block by one wave (lane = equation) ---------------------
@@ -145,10 +221,11 @@ template <bool TRANS>
 __global__ __launch_bounds__(64) void trsv_diag_kernel(const double* __restrict__ L, long ldl, int nb, double* __restrict__ x) {
     __shared__ double T[NB * (NB + 1)];
     const int lane = threadIdx.x;
-    for (int r = 0; r < NB; ++r) {
-        double v = (r == lane) ? 1.0 : 0.0;
-        if (r < nb && lane < nb) v = L[(long)r * ldl + lane];
-        T[r * (NB + 1) + lane] = v;
+    {
+        double t[NB];
+        load_rows(L, ldl, nb, nb, lane, t);
+#pragma unroll
+        for (int r = 0; r < NB; ++r) T[r * (NB + 1) + lane] = (r < nb && lane < nb) ? t[r] : ((r == lane) ? 1.0 : 0.0);
     }
     __syncthreads();
     double b = (lane < nb) ? x[lane] : 0.0;
@@ -188,9 +265,16 @@ __global__ __launch_bounds__(256) void gemv_cols_kernel(const double* __restrict
                                                         const double* __restrict__ x, double* __restrict__ y) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
-    double s = 0.0;
-    for (int j = 0; j < rows; ++j) s += A[(long)j * lda + c] * x[j];
-    y[c] -= s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = 0;
+    for (; j + 4 <= rows; j += 4) {
+        s0 += A[(long)j * lda + c] * x[j];
+        s1 += A[(long)(j + 1) * lda + c] * x[j + 1];
+        s2 += A[(long)(j + 2) * lda + c] * x[j + 2];
+        s3 += A[(long)(j + 3) * lda + c] * x[j + 3];
+    }
+    for (; j < rows; ++j) s0 += A[(long)j * lda + c] * x[j];
+    y[c] -= (s0 + s1) + (s2 + s3);
 }
 
 __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x, const double* __restrict__ y, int n, double* out) {
@@ -207,6 +291,9 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
     }
 }
 
+int g_dbg = 0;
+int g_mt_trsm = 0;
+
 inline int split(int n) {
     // first part: about half, a multiple of 128 when there is room (keeps GEMM operands aligned and tiles full)
     const int q = (n > 256) ? 128 : NB;
@@ -222,8 +309,8 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
     if (n <= 0 || nrhs <= 0) return 0;
     if (n <= NB) {
         dim3 grid(gpk_ceil_div(nrhs, NB));
-        if (trans) trsm_base_kernel<true, false><<<grid, 64, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs);
-        else       trsm_base_kernel<false, false><<<grid, 64, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs);
+        if (trans) trsm_base_kernel<true, false><<<grid, 64, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
+        else       trsm_base_kernel<false, false><<<grid, 64, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -243,10 +330,51 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
     return 0;
 }
 
+// The 64-row diagonal solves of a multi-RHS TRSM keep only nrhs/64 waves busy and sit on the critical path between
+// the GEMM updates.  Column groups of the right-hand side are independent, so they are issued on separate streams:
+// while one group runs a (latency-bound) diagonal solve the other groups' GEMMs fill the chip.
+int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+    constexpr int G = 4;
+    // Measured at N=8400, nrhs=4001 (round 1): 17.9 ms with 4 groups vs 11.0 ms single-stream -- four times as many
+    // launches of smaller GEMMs cost more than the overlap buys.  Kept behind gpk_debug_set(2, 1) for re-evaluation
+    // once the diagonal solves are fused into fewer launches.
+    if (!g_mt_trsm || nrhs < 1024 || n <= 2 * NB) return gpk_i_trsm_left(h, trans, L, n, ldl, B, nrhs, ldb);
+    if (!h->ev_fork) {
+        GPK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < G - 1; ++i) {
+            GPK_HIP(h, hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+            GPK_HIP(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+    }
+    const int per = ((nrhs / G + 127) / 128) * 128;                  // group width, multiple of 128 columns
+    hipStream_t main_stream = h->stream;
+    GPK_HIP(h, hipEventRecord(h->ev_fork, main_stream));
+    int rc = 0;
+    for (int g = 0; g < G && rc == 0; ++g) {
+        const int c0 = g * per;
+        if (c0 >= nrhs) break;
+        const int w = (nrhs - c0 < per || g == G - 1) ? nrhs - c0 : per;
+        if (g > 0) {
+            h->stream = h->side[g - 1];
+            hipError_t e = hipStreamWaitEvent(h->stream, h->ev_fork, 0);
+            if (e != hipSuccess) { h->stream = main_stream; return gpk_fail(h, e, "hipStreamWaitEvent", __FILE__, __LINE__); }
+        }
+        rc = gpk_i_trsm_left(h, trans, L, n, ldl, B + c0, w, ldb);
+        if (g > 0) {
+            hipError_t e = hipEventRecord(h->ev_join[g - 1], h->stream);
+            h->stream = main_stream;
+            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, h->ev_join[g - 1], 0);
+            if (e != hipSuccess) return gpk_fail(h, e, "join", __FILE__, __LINE__);
+        }
+    }
+    h->stream = main_stream;
+    return rc;
+}
+
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {
     if (n <= 0 || m <= 0) return 0;
     if (n <= NB) {
-        trsm_base_kernel<false, true><<<gpk_ceil_div(m, NB), 64, 0, h->stream>>>(L, ldl, n, X, ldx, m);
+        trsm_base_kernel<false, true><<<gpk_ceil_div(m, NB), 64, 0, h->stream>>>(L, ldl, n, X, ldx, m, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -260,20 +388,42 @@ int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X
     return 0;
 }
 
+// Two-level right-looking Cholesky.
+//   outer panels of OB columns: after a panel is factored, ONE large SYRK (K = OB, lower tiles only) updates the
+//   trailing matrix on the MFMA units;
+//   inside a panel, steps of NB = 64 columns, three launches each, every one covering ALL rows of the panel:
+//     potf2 (diagonal block)  ->  substitution of the rows below  ->  rank-64 update of the panel's remaining columns.
+// (A plain recursion needs ~15 launches per 64 columns, most of them a single wave.)
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     if (n <= 0) return 0;
-    if (n <= NB) {
-        potf2_kernel<<<1, 64, 0, h->stream>>>(A, lda, n, h->d_info, pivot_base);
+    constexpr int OB = 512;
+    for (int k0 = 0; k0 < n; k0 += OB) {
+        const int ob = (n - k0 < OB) ? n - k0 : OB;
+        for (int j0 = k0; j0 < k0 + ob; j0 += NB) {
+            const int nb = (k0 + ob - j0 < NB) ? k0 + ob - j0 : NB;
+            double* Ajj = A + (long)j0 * lda + j0;
+            potf2_kernel<<<1, 64, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
+            const int below = n - (j0 + nb);
+            if (below > 0) {
+                double* Abj = A + (long)(j0 + nb) * lda + j0;
+                trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 64, 0, h->stream>>>(Ajj, lda, nb, Abj, lda, below, g_dbg);
+                const int pc = k0 + ob - (j0 + nb);                   // remaining columns of this outer panel
+                if (pc > 0) {
+                    // A[j0+nb:, j0+nb : k0+ob] -= L[j0+nb:, j] * L[j0+nb : k0+ob, j]^T   (rows above the diagonal
+                    // of that block are computed too; they are never read)
+                    GPK_TRY(gpk_i_gemm(h, false, true, below, pc, nb, -1.0, Abj, lda, Abj, lda, 1.0,
+                                       A + (long)(j0 + nb) * lda + (j0 + nb), lda, false));
+                }
+            }
+        }
         GPK_LAUNCH_CHECK(h);
-        return 0;
+        const int rest = n - (k0 + ob);
+        if (rest > 0) {
+            double* P = A + (long)(k0 + ob) * lda + k0;               // factored panel rows below the outer block
+            GPK_TRY(gpk_i_gemm(h, false, true, rest, rest, ob, -1.0, P, lda, P, lda, 1.0,
+                               A + (long)(k0 + ob) * lda + (k0 + ob), lda, true));
+        }
     }
-    const int n1 = split(n), n2 = n - n1;
-    double* A21 = A + (long)n1 * lda;
-    double* A22 = A21 + n1;
-    GPK_TRY(gpk_i_potrf(h, A, n1, lda, pivot_base));
-    GPK_TRY(gpk_i_trsm_right_lt(h, A, n1, lda, A21, n2, lda));
-    GPK_TRY(gpk_i_gemm(h, false, true, n2, n2, n1, -1.0, A21, lda, A21, lda, 1.0, A22, lda, true));
-    GPK_TRY(gpk_i_potrf(h, A22, n2, lda, pivot_base + n1));
     return 0;
 }
 
@@ -307,6 +457,15 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------
+extern "C" int gpk_debug_set_mt_trsm(int v) { g_mt_trsm = v; return 0; }
+
+extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
+    if (!h) return GPK_ERR_ARG;
+    g_dbg = enable;
+    if (host16) GPK_HIP(h, hipMemcpyFromSymbol(host16, HIP_SYMBOL(gpk_dbg_stamps), 16 * sizeof(unsigned long long)));
+    return 0;
+}
+
 extern "C" int gpk_potrf(gpk_handle h, double* A, int n, int lda, int* host_info) {
     if (!h || !A || n < 0 || lda < n) return GPK_ERR_ARG;
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
@@ -321,7 +480,7 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int n, int lda, int* host_info
 extern "C" int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
     if (!h || !L || !B || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs) return GPK_ERR_ARG;
     if (nrhs == 1 && ldb == 1) return gpk_i_trsv(h, trans != 0, L, n, ldl, B);
-    return gpk_i_trsm_left(h, trans != 0, L, n, ldl, B, nrhs, ldb);
+    return gpk_i_trsm_left_mt(h, trans != 0, L, n, ldl, B, nrhs, ldb);
 }
 
 extern "C" int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {

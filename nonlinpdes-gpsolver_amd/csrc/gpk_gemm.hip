@@ -226,6 +226,16 @@ __global__ void tril_kernel(double* A, int n, long lda) {
 
 }  // namespace
 
+static int g_force_cfg = 0;          // development aid (gpk_debug_set key 0): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
+
+extern "C" int gpk_debug_set_mt_trsm(int v);
+
+extern "C" int gpk_debug_set(int key, int value) {
+    if (key == 0) { g_force_cfg = value; return 0; }
+    if (key == 2) return gpk_debug_set_mt_trsm(value);
+    return GPK_ERR_ARG;
+}
+
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
                const double* B, int ldb, double beta, double* C, int ldc, bool lower_only) {
     if (m <= 0 || n <= 0) return 0;
@@ -240,7 +250,10 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // big tiles once they fill the chip (256 CUs x 2 resident workgroups); small tiles keep more CUs busy otherwise
     const long tm = gpk_ceil_div(m, 128), tn = gpk_ceil_div(n, 128);
     const long big_tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
-    if (big_tiles >= 384) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
+    // measured (tools/gemm_sweep.py): the 64x64 configuration matches or beats 128x128 up to ~1500 big tiles (less
+    // tail quantisation over 256 CUs); the big tiles win once there are >= 6 of them per CU
+    const bool big = g_force_cfg ? (g_force_cfg == 1) : (big_tiles >= ((ta && !tb && !lower_only) ? 900 : 1536));
+    if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
     return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
 }
 

@@ -163,7 +163,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
     GPK_TRY(build(h, p, z, S, lds, d.nz, 1));
     for (int k = 0; k < d.ngroups; ++k)
-        if (d.g[k].L) GPK_TRY(gpk_i_trsm_left(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
+        if (d.g[k].L) GPK_TRY(gpk_i_trsm_left_mt(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
     GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, S, lds, S, lds, 0.0, Hb, ldh, true));
     return 0;
 }

@@ -56,6 +56,8 @@ PROTOTYPES = {
     'gpk_gn_loss': (_i, [_vp, _pp, _vp, _vp, _pd]),
     'gpk_gn_hessian_grad': (_i, [_vp, _pp, _vp, _vp, _i, _vp, _i, _vp]),
     'gpk_gn_measurement': (_i, [_vp, _pp, _vp, _vp]),
+    'gpk_debug_set': (_i, [_i, _i]),
+    'gpk_debug_stamps': (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     'gpk_ubench_mfma_f64': (_i, [_vp, _i, _pd]),
     'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
 }

@@ -160,6 +160,11 @@ class Context:
             return DeviceArray(self, a.size).upload(a)
         return DeviceArray(self, a.shape[0], a.shape[1]).upload(a)
 
+    def points(self, X):
+        """(n,2) point set, contiguous (ld = 2) as the C ABI expects"""
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 2)
+        return DeviceArray(self, max(X.shape[0], 1), 2, ld=2).upload(X) if X.shape[0] else DeviceArray(self, 1, 2, ld=2)
+
     def timer_start(self):
         self._chk(self.lib.gpk_timer_start(self.h))
 
@@ -174,7 +179,7 @@ class Context:
         Nd, Nb = Xd.shape[0], Xb.shape[0]
         lay = LAYOUT[layout]
         N = {0: 2 * Nd + Nb, 1: 4 * Nd + Nb, 2: 4 * Nd + Nb, 3: 3 * Nd}[lay]
-        dXd = self.array(Xd); dXb = self.array(Xb) if Nb else DeviceArray(self, 1, 2)
+        dXd, dXb = self.points(Xd), self.points(Xb)
         T = out if out is not None else DeviceArray(self, N, N)
         ratios = (C.c_double * 3)()
         self._chk(self.lib.gpk_assemble(self.h, lay, KERNEL[kernel], kernel_params(kernel, kernel_parameter),
@@ -188,8 +193,7 @@ class Context:
         Nt, Nd, Nb = Xt.shape[0], Xd.shape[0], Xb.shape[0]
         lay = LAYOUT[layout]
         N = {0: 2 * Nd + Nb, 1: 4 * Nd + Nb, 2: 4 * Nd + Nb, 3: 3 * Nd}[lay]
-        dXt, dXd = self.array(Xt), self.array(Xd)
-        dXb = self.array(Xb) if Nb else DeviceArray(self, 1, 2)
+        dXt, dXd, dXb = self.points(Xt), self.points(Xd), self.points(Xb)
         out = DeviceArray(self, Nt, N)
         self._chk(self.lib.gpk_assemble_test(self.h, lay, KERNEL[kernel], kernel_params(kernel, kernel_parameter),
                                              dXt.ptr, Nt, dXd.ptr, Nd, dXb.ptr, Nb, out.ptr, out.ld))
@@ -200,8 +204,7 @@ class Context:
         Xt = np.ascontiguousarray(Xt, dtype=np.float64); Xd = np.ascontiguousarray(Xd, dtype=np.float64)
         Xb = np.ascontiguousarray(Xb, dtype=np.float64).reshape(-1, 2)
         Nt, Nd, Nb = Xt.shape[0], Xd.shape[0], Xb.shape[0]
-        dXt, dXd = self.array(Xt), self.array(Xd)
-        dXb = self.array(Xb) if Nb else DeviceArray(self, 1, 2)
+        dXt, dXd, dXb = self.points(Xt), self.points(Xd), self.points(Xb)
         dc = coeff if isinstance(coeff, DeviceArray) else self.array(coeff)
         out = DeviceArray(self, Nt)
         self._chk(self.lib.gpk_extend(self.h, LAYOUT[layout], KERNEL[kernel], kernel_params(kernel, kernel_parameter),
