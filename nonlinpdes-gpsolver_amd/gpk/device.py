@@ -59,6 +59,12 @@ class DeviceArray:
             self.ctx._chk(self.ctx.lib.gpk_memcpy2d_d2h(self.ctx.h, out.ctypes.data, cols * 8, src, self.ld * 8, cols * 8, rows))
         return out[:, 0] if (self.cols == 1 and cols == 1) else out
 
+    def clone(self):
+        """device-to-device copy (same shape and leading dimension)"""
+        out = DeviceArray(self.ctx, self.rows, self.cols, self.ld)
+        self.ctx._chk(self.ctx.lib.gpk_memcpy_d2d(self.ctx.h, out.ptr, self.ptr, self.nbytes))
+        return out
+
     def at(self, row=0, col=0):
         return self.ptr + (row * self.ld + col) * 8
 

@@ -1,0 +1,183 @@
+"""End-to-end GPU tests THROUGH THE REFERENCE-SHAPED API (src.solver.solver_GP, src.PDEs, src.InverseProblems,
+src.Gram_matrice): the same call sequence as the reference's main_*.py, compared with fixtures produced by running the
+reference's own classes (tests/golden/solves.npz).  Bound: solution / extension vectors within 1e-6 relative
+(north-star), loss histories within 1e-5 at nugget >= 1e-8."""
+import argparse
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope='module')
+def solves():
+    return np.load(os.path.join(G, 'solves.npz'))
+
+
+def _u(x1, x2):
+    return np.sin(np.pi * x1) * np.sin(np.pi * x2) + 2 * np.sin(4 * np.pi * x1) * np.sin(4 * np.pi * x2)
+
+
+def _f(alpha, m):
+    return lambda x1, x2: (2 * np.pi ** 2 * np.sin(np.pi * x1) * np.sin(np.pi * x2)
+                           + 64 * np.pi ** 2 * np.sin(4 * np.pi * x1) * np.sin(4 * np.pi * x2) + alpha * _u(x1, x2) ** m)
+
+
+def test_gram_matrix_assembly_function(solves):
+    from src.Gram_matrice import Gram_matrix_assembly, construct_Theta_test
+    d = np.load(os.path.join(G, 'theta_small.npz'))
+    n = 'darcy_gauss'
+    Tu, Ta = Gram_matrix_assembly(d[n + '__Xd'], d[n + '__Xb'], eqn='Darcy_flow2d', kernel='Gaussian', kernel_parameter=0.2)
+    assert np.max(np.abs(Tu - d[n + '__Theta_u'])) <= 4e-15 * np.max(np.abs(Tu))
+    assert np.max(np.abs(Ta - d[n + '__Theta_a'])) <= 4e-15 * np.max(np.abs(Ta))
+    Ttu, Tta = construct_Theta_test(d[n + '__Xt'], d[n + '__Xd'], d[n + '__Xb'], eqn='Darcy_flow2d')
+    assert np.max(np.abs(Ttu - d[n + '__Theta_u_test'])) <= 4e-15 * np.max(np.abs(Ttu))
+    assert Gram_matrix_assembly(d[n + '__Xd'], d[n + '__Xb'], eqn='nonsense') is None       # reference falls through
+
+
+def test_elliptic_through_solver_gp(solves, capsys):
+    from src.solver import solver_GP
+    d, p = solves, 'elliptic_small'
+    alpha, m, sigma, nug, steps, seed = d[p + '__params']
+    cfg = argparse.Namespace(alpha=alpha, m=m, kernel='Gaussian', kernel_parameter=sigma, nugget=nug, nugget_type='adaptive',
+                             GNsteps=int(steps), step_size=1, initial_sol='rdm', print_hist=True)
+    np.random.seed(int(seed))                                   # same seed as the reference run -> identical points
+    s = solver_GP(cfg, PDE_type='Nonlinear_elliptic')
+    s.set_equation(bdy=_u, rhs=_f(alpha, m), domain=np.array([[0, 1], [0, 1]]))
+    s.auto_sample(300, 60, sampled_type='random')
+    assert np.array_equal(s.eqn.X_domain, d[p + '__X_domain']) and np.array_equal(s.eqn.X_boundary, d[p + '__X_boundary'])
+    s.solve(method='elimination')
+    np.testing.assert_array_equal(s.eqn.init_sol, d[p + '__init_sol'])         # RNG consumed in the reference's order
+    np.testing.assert_allclose(s.eqn.loss_hist, d[p + '__loss_hist'], rtol=1e-5)
+    assert s.eqn.ratio == pytest.approx(float(d[p + '__ratio'][0]), rel=1e-13)
+    assert _rel(s.eqn.sol_sampled_pts, d[p + '__sol']) < 1e-6
+    assert _rel(s.eqn.sol_vec, d[p + '__sol_vec']) < 1e-6
+    s.collocation_pts_err(_u(s.eqn.X_domain[:, 0], s.eqn.X_domain[:, 1]))
+    s.test(d[p + '__X_test'])
+    assert _rel(s.eqn.extended_sol, d[p + '__extended_sol']) < 1e-6
+    s.get_test_error(_u(d[p + '__X_test'][:, 0], d[p + '__X_test'][:, 1]))
+    out = capsys.readouterr().out
+    for line in ('[Equation type] Nonlinear elliptic equation', '[Kernel] Gaussian', '[Gauss Newton] elimination approaches',
+                 'iter = 0 Loss =', 'Gauss-Newton step size = 1', '[Collocation point error] L2 error', '[Test error] Max error'):
+        assert line in out, line
+    # attribute surface
+    L = s.eqn.L
+    assert L.shape == (660, 660) and np.allclose(np.triu(L, 1), 0)
+    assert np.linalg.norm(L @ L.T - s.eqn.Theta) <= 1e-12 * np.linalg.norm(s.eqn.Theta)
+    # loss / grad / Hessian API
+    z = d[p + '__sol']
+    assert s.eqn.loss(z) == pytest.approx(d[p + '__loss_hist'][-1], rel=1e-5)
+    H = s.eqn.Hessian_GN(z, z); g = s.eqn.grad_loss(z)
+    assert H.shape == (300, 300) and g.shape == (300,) and np.array_equal(H, H.T)
+    assert s.eqn.GN_loss(z, z) > 0
+
+
+def test_elliptic_relaxation_through_solver_gp(solves):
+    from src.solver import solver_GP
+    d, p = solves, 'elliptic_relaxed'
+    alpha, m, sigma, nug, steps, seed, lam = d[p + '__params']
+    cfg = argparse.Namespace(alpha=alpha, m=m, kernel='Gaussian', kernel_parameter=sigma, nugget=nug, nugget_type='adaptive',
+                             GNsteps=int(steps), step_size=1, initial_sol='rdm', print_hist=False)
+    np.random.seed(int(seed))
+    s = solver_GP(cfg, PDE_type='Nonlinear_elliptic')
+    s.set_equation(bdy=_u, rhs=_f(alpha, m), domain=np.array([[0, 1], [0, 1]]), print_option=False)
+    s.auto_sample(120, 40, print_option=False)
+    s.solve(method='relaxation', pen_lambda=lam, print_option=False)
+    np.testing.assert_allclose(s.eqn.loss_hist, d[p + '__loss_hist'], rtol=1e-5)
+    assert _rel(s.eqn.sol_sampled_pts, d[p + '__sol']) < 1e-6
+
+
+def test_burgers_through_solver_gp(solves):
+    from src.solver import solver_GP
+    d, p = solves, 'burgers_small'
+    alpha, nu, st, sx, nug, steps, seed = d[p + '__params']
+    cfg = argparse.Namespace(alpha=alpha, nu=nu, kernel='anisotropic_Gaussian', kernel_parameter=[st, sx], nugget=nug,
+                             nugget_type='adaptive', GNsteps=int(steps), step_size=1, initial_sol='rdm', print_hist=False)
+    np.random.seed(int(seed))
+    s = solver_GP(cfg, PDE_type='Burgers')
+    s.set_equation(bdy=lambda x1, x2: -np.sin(np.pi * x2) * (x1 == 0) + 0 * (x2 == 0), rhs=lambda x1, x2: 0,
+                   domain=np.array([[0, 1], [-1, 1]]), print_option=False)
+    s.auto_sample(200, 60, print_option=False)
+    assert s.eqn.N_boundary == 60 and np.array_equal(s.eqn.X_domain, d[p + '__X_domain'])
+    s.solve(print_option=False)
+    np.testing.assert_allclose(s.eqn.loss_hist, d[p + '__loss_hist'], rtol=1e-6)
+    np.testing.assert_allclose(s.eqn.ratio, d[p + '__ratio'], rtol=1e-13)
+    assert _rel(s.eqn.sol_sampled_pts, d[p + '__sol']) < 1e-6
+    s.test(d[p + '__X_test'], print_option=False)
+    assert _rel(s.eqn.extended_sol, d[p + '__extended_sol']) < 1e-6
+    assert s.eqn.Hessian_GN(s.eqn.init_sol).shape == (600, 600)
+
+
+def test_eikonal_through_solver_gp(solves):
+    from src.solver import solver_GP
+    d, p = solves, 'eikonal_small'
+    eps, sigma, nug, steps, seed = d[p + '__params']
+    cfg = argparse.Namespace(eps=eps, kernel='Gaussian', kernel_parameter=sigma, nugget=nug, nugget_type='adaptive',
+                             GNsteps=int(steps), step_size=1, initial_sol='zero', print_hist=False)
+    np.random.seed(int(seed))
+    s = solver_GP(cfg, PDE_type='Eikonal')
+    s.set_equation(bdy=lambda x1, x2: 0, rhs=lambda x1, x2: 1, domain=np.array([[0, 1], [0, 1]]), print_option=False)
+    s.auto_sample(200, 48, print_option=False)
+    s.solve(print_option=False)
+    np.testing.assert_allclose(s.eqn.loss_hist, d[p + '__loss_hist'], rtol=1e-6)
+    assert _rel(s.eqn.sol_sampled_pts, d[p + '__sol']) < 1e-6
+    s.test(d[p + '__X_test'], print_option=False)
+    assert _rel(s.eqn.extended_sol, d[p + '__extended_sol']) < 1e-6
+
+
+def test_darcy_through_solver_gp(solves):
+    from src.solver import solver_GP
+    d, p = solves, 'darcy_small'
+    sigma, nug, steps, seed, ndata, noise = d[p + '__params']
+    cfg = argparse.Namespace(kernel='Gaussian', kernel_parameter=sigma, nugget=nug, nugget_type='adaptive',
+                             GNsteps=int(steps), step_size=1, initial_sol='rdm', print_hist=False)
+    np.random.seed(int(seed))
+    s = solver_GP(cfg, PDE_type='Darcy_flow2d')
+    s.set_equation(bdy=lambda x1, x2: 0, rhs=lambda x1, x2: 1, domain=np.array([[0, 1], [0, 1]]), print_option=False)
+    s.auto_sample_IP(150, 40, int(ndata), print_option=False)
+    s.get_observed_data(d[p + '__data_clean'], noise, print_option=False)      # noise drawn here, as in the reference run
+    np.testing.assert_array_equal(s.eqn.data_u, d[p + '__data_u'])
+    s.solve(print_option=False)
+    np.testing.assert_allclose(s.eqn.loss_hist, d[p + '__loss_hist'], rtol=1e-6)
+    assert _rel(s.eqn.sol_vec_a, d[p + '__sol_vec_a']) < 1e-6 and _rel(s.eqn.sol_vec_u, d[p + '__sol_vec_u']) < 1e-6
+    s.test(d[p + '__X_test'], print_option=False)
+    assert _rel(s.eqn.extended_sol_a, d[p + '__extended_sol_a']) < 1e-6
+    assert _rel(s.eqn.extended_sol_u, d[p + '__extended_sol_u']) < 1e-6
+
+
+def test_readme_command_line_runs():
+    """BASELINE config 1: the reference README's command line against our driver; L2 errors of the reference run
+    (2.24e-7 collocation, 2.56e-7 test at seed 0) are reproduced to the digit that conditioning allows (< 1e-6)."""
+    env = dict(os.environ)
+    code = ("import numpy, runpy, sys; numpy.random.seed(0); "
+            "sys.argv=['main_NonLinElliptic2d.py','--kernel','Gaussian','--kernel_parameter','0.2','--nugget','1e-13',"
+            "'--N_domain','900','--N_boundary','124','--GNsteps','4','--show_figure','']; "
+            "runpy.run_path('main_NonLinElliptic2d.py', run_name='__main__')")
+    r = subprocess.run([sys.executable, '-c', code], cwd=os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert '[Sample points] N_domain = 900, N_boundary = 124' in out
+    l2 = [float(l.split('L2 error')[1]) for l in out.splitlines() if 'L2 error' in l]
+    assert len(l2) == 2 and all(v < 1e-6 for v in l2), out[-1500:]
+
+
+def test_other_drivers_run_small():
+    pkg = os.path.join(ROOT, 'nonlinpdes-gpsolver_amd')
+    for args in (['main_Burgers1d.py', '--N_domain', '300', '--N_boundary', '90', '--GNsteps', '6', '--show_figure', ''],
+                 ['main_Eikonal2d.py', '--N_domain', '300', '--N_boundary', '80', '--GNsteps', '6', '--show_figure', ''],
+                 ['main_DarcyFlow2d.py', '--N_domain', '200', '--N_boundary', '60', '--N_data', '30', '--GNsteps', '6', '--show_figure', '']):
+        r = subprocess.run([sys.executable] + args, cwd=pkg, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (args, r.stderr[-2000:])
+        assert '[Gauss Newton] Gauss Newton iteration finished' in r.stdout and 'nan' not in r.stdout.lower(), r.stdout[-1500:]
