@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Gauss-Newton steps/sec (+ L2 error) of the GP solver for NonLinElliptic2d on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W                  BASELINE config 2: N_domain=4000, N_boundary=400
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W                  BASELINE config 5: N_domain=16000, N_boundary=2000,
+                                                                   panel-sharded over N ranks (RCCL), strong scaling
+    python bench.py --gpus 1 --workload c5                         the 1-GPU point of the config-5 scaling curve
+
+A "step" is one Gauss-Newton step of the reference's GN_method (src/PDEs.py:117-127): Hessian_GN + grad_loss + linear
+solve + update + one loss evaluation, executed as TRSM (n_z+1 right-hand sides) + SYRK + Cholesky of H + triangular
+solve, all operands resident in HBM.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded inside the timed steps on the
+stream the kernels run on; `cpu_baseline` times the CPU oracle (reference operation sequence) on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'nonlinpdes-gpsolver_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X datasheet fp64 matrix rate (= 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz); the local
+                                  # guides state no fp64 peak.  v_mfma_f64_16x16x4_f64 issue-rate ubench: ~74.
+HBM_PEAK_GBS = 8000.0             # /opt/skills/guides/MI355X_MICROARCH.md:35 (6290 GB/s measured achievable)
+
+WORKLOADS = {
+    # name: (N_domain, N_boundary, GNsteps of the reference config, description)
+    'c1': (900, 124, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=900 N_boundary=124 (BASELINE config 1)'),
+    'c2': (4000, 400, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=4000 N_boundary=400 (BASELINE config 2)'),
+    'c5': (16000, 2000, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=16000 N_boundary=2000 (BASELINE config 5)'),
+}
+SIGMA, ALPHA, M_EXP = 0.2, 1.0, 3.0
+
+
+def u_true(x1, x2):
+    return np.sin(np.pi * x1) * np.sin(np.pi * x2) + 2 * np.sin(4 * np.pi * x1) * np.sin(4 * np.pi * x2)
+
+
+def rhs(x1, x2):        # -Laplace(u*) + alpha u*^m, main_NonLinElliptic2d.py:60-64 of the reference
+    return (2 * np.pi ** 2 * np.sin(np.pi * x1) * np.sin(np.pi * x2)
+            + 64 * np.pi ** 2 * np.sin(4 * np.pi * x1) * np.sin(4 * np.pi * x2) + ALPHA * u_true(x1, x2) ** M_EXP)
+
+
+def synthetic_problem(Nd, Nb):
+    """numpy.random.seed(0), the reference sampler's draw order, then the N(0,1) initial guess."""
+    from src.sample_points import sampled_pts_rdm
+    np.random.seed(0)
+    Xd, Xb = sampled_pts_rdm(Nd, Nb, np.array([[0, 1], [0, 1]]), time_dependent=False)
+    z0 = np.random.normal(0.0, 1.0, Nd)
+    return Xd, Xb, rhs(Xd[:, 0], Xd[:, 1]), u_true(Xb[:, 0], Xb[:, 1]), z0
+
+
+def test_grid(n=60):
+    xx = np.linspace(0, 1, n)
+    XX, YY = np.meshgrid(xx, xx)
+    return np.concatenate((XX.reshape(-1, 1), YY.reshape(-1, 1)), axis=1)
+
+
+def f1_flops(N, nz):
+    return float(N) * N * nz + float(N) * nz * nz + nz ** 3 / 3.0
+
+
+# ------------------------------------------------------------------------------------------------------ single GPU
+def run_single(args, workload):
+    import torch
+    import gpk
+    Nd, Nb, _, desc = WORKLOADS[workload]
+    N, nz = 2 * Nd + Nb, Nd
+    ctx = gpk.Context(0)
+    Xd, Xb, f, g, z0 = synthetic_problem(Nd, Nb)
+
+    # one-time phases (reported, not part of the metric): assembly (HBM-write bound) and Cholesky of Theta
+    dXd, dXb = ctx.points(Xd), ctx.points(Xb)
+    T = ctx.empty(N, N)
+    kp = gpk.device.kernel_params('Gaussian', SIGMA)
+    ratios = (C.c_double * 3)()
+    nugget, info = 1e-13, -1
+    asm_ms = chol_ms = None
+    while True:
+        for rep in range(3):                                      # warm + 2 timed
+            ctx.timer_start()
+            ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, dXd.ptr, Nd, dXb.ptr, Nb, nugget, 2, T.ptr, T.ld, ratios))
+            ms = ctx.timer_stop()
+            asm_ms = ms if rep == 1 else min(asm_ms or ms, ms)
+        ctx.timer_start()
+        info = ctx.potrf(T)
+        chol_ms = ctx.timer_stop()
+        if info == 0 or nugget >= 1e-8:
+            break
+        nugget *= 10.0                                            # SURVEY 7 hard part 1: report the nugget actually used
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=ALPHA, p1=M_EXP)
+    z = ctx.array(z0)
+    prob.workspace()
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(ctx.gn_step(prob, z)[0])
+    ctx.prof_enable(True)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(ctx.gn_step(prob, z)[0])
+    ctx.synchronize(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    losses.append(ctx.gn_loss(prob, z))
+
+    # accuracy half of the metric
+    sol = z.download()
+    pts_l2 = float(np.sqrt(np.sum((u_true(Xd[:, 0], Xd[:, 1]) - sol) ** 2) / Nd))
+    Xt = test_grid(60)
+    coeff = ctx.array(np.concatenate([ALPHA * sol ** M_EXP - f, sol, g]))
+    ctx.potrs(T, coeff, nrhs=1)
+    ext = ctx.extend('Nonlinear_elliptic', 'Gaussian', SIGMA, Xt, Xd, Xb, coeff).download()
+    test_l2 = float(np.sqrt(np.sum((u_true(Xt[:, 0], Xt[:, 1]) - ext) ** 2) / Xt.shape[0]))
+
+    steps = max(prof['steps'], 1)
+    syrk_ms = prof['syrk_ms'] / steps
+    syrk_flops = float(N) * (nz + 1) ** 2                        # symmetric count, SURVEY 8d ("SYRK N n_z^2")
+    achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_syrk.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    out = {
+        'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
+        'value': args.steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz,
+                   'kernel': 'Gaussian', 'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive',
+                   'formulation': 'dense F1: TRSM(n_z+1 rhs) + SYRK + POTRF(H) + TRSV per step, nothing cached', 'seed': 0},
+        'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': args.warmup + args.steps,
+                     'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
+        'f1_tflops': f1_flops(N, nz) * args.steps / elapsed / 1e12,
+        'phases_ms_per_step': {'trsm': prof['trsm_ms'] / steps, 'syrk': syrk_ms, 'potrf_H': prof['potrf_ms'] / steps,
+                               'trsv_update': prof['trsv_update_ms'] / steps},
+        'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms},
+        'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<TN, lower tiles> = SYRK Hb = S^T S',
+                     'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
+                     'traffic': traffic, 'flops_per_launch': syrk_flops, 'avg_launch_ms': syrk_ms,
+                     'peak_source': 'datasheet fp64 matrix rate; v_mfma_f64_16x16x4_f64 issue-rate ubench on this chip ~74'},
+        'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble_kernel<elliptic>', 'achieved': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'bytes_per_launch': 8.0 * N * N},
+    }
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(T, N, Nd, Nb, f, g, z0)
+    ctx.close()
+    return out
+
+
+def cpu_baseline(T, N, Nd, Nb, f, g, z0):
+    """The CPU oracle on this box's host cores, full workload size, ONE Gauss-Newton step:
+    B1 = the reference's operation sequence (general LU solves of the triangular L for Hessian, gradient and loss, LU
+    solve of H: src/PDEs.py:86,97,118) -- the stand-in for 'reference JAX on CPU', which cannot be installed here;
+    B2 = the triangular formulation the GPU path uses, on the same BLAS."""
+    from oracle import gp_oracle as O
+    L = np.tril(T.download())
+    sysm = O.EllipticSystem(ALPHA, M_EXP, f, g)
+    t0 = time.perf_counter()
+    H, grad = O.gn_quantities(sysm, [L], z0, faithful=True)
+    z1 = z0 - np.linalg.solve(H, grad)
+    O.loss(sysm, [L], z1, faithful=True)
+    t_b1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.gn_method(sysm, [L], z0, 1, 1, faithful=False)
+    t_b2 = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {'value': 1.0 / t_b1, 'unit': 'GN steps/s', 'cores': threads, 'kind': 'port',
+            'sample': f'1 Gauss-Newton step at the full workload size (N={N}, n_z={Nd}), reference operation sequence '
+                      f'(3 general LU solves of L + LU solve of H) with numpy/scipy BLAS; factor L taken from the device',
+            'seconds_per_step': t_b1, 'triangular_formulation_value': 1.0 / t_b2, 'triangular_seconds_per_step': t_b2,
+            'host_cpus': os.cpu_count()}
+
+
+# ------------------------------------------------------------------------------------------------------ sharded
+def run_sharded(args, workload):
+    import torch
+    import torch.distributed as dist
+    import gpk
+    from gpk._lib import GNProblemStruct
+    from gpk.sharded import Comm, GpuBlockOps, ShardedFactorSolve
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    use_pg = world > 1 or os.environ.get('GPK_FORCE_PG') == '1'
+    if use_pg:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl')
+    dev = torch.device('cuda', local)
+    Nd, Nb, _, desc = WORKLOADS[workload]
+    N, nz = 2 * Nd + Nb, Nd
+    ctx = gpk.Context(local)
+    ops = GpuBlockOps(ctx)                                        # libgpk now runs on torch's current stream
+    comm = Comm()
+    solver = ShardedFactorSolve(ops, comm, nb=args.panel)
+    Xd, Xb, f, g, z0 = synthetic_problem(Nd, Nb)                  # identical on every rank (seeded)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+    tXd, tXb, tf, tg, z = t(Xd), t(Xb), t(f), t(g), t(z0)
+    ld = ((N + 15) // 16) * 16
+    Theta = torch.empty((N, ld), dtype=torch.float64, device=dev)
+    kp = gpk.device.kernel_params('Gaussian', SIGMA)
+    ratios = (C.c_double * 3)()
+    nugget = 1e-13
+    while True:
+        # assembly shards trivially (every entry depends on two points); at 9.2 GB / 5 TB/s it is cheaper to let
+        # every rank write the whole matrix than to communicate anything
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, tXd.data_ptr(), Nd, tXb.data_ptr(), Nb, nugget, 2, Theta.data_ptr(), ld, ratios))
+        torch.cuda.synchronize(); asm_ms = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        info = solver.potrf(Theta, N)
+        torch.cuda.synchronize(); chol_ms = 1e3 * (time.perf_counter() - t0)
+        if info == 0 or nugget >= 1e-8:
+            break
+        nugget *= 10.0
+    ps = GNProblemStruct()
+    ps.system, ps.Nd, ps.Nb, ps.Ndata = 0, Nd, Nb, 0
+    ps.p0, ps.p1, ps.pen_lambda = ALPHA, M_EXP, 0.0
+    ps.rhs_f, ps.bdy_g, ps.data_u = tf.data_ptr(), tg.data_ptr(), None
+    ps.L, ps.ldl, ps.L2, ps.ldl2 = Theta.data_ptr(), ld, None, 0
+    lds = ((nz + 1 + 15) // 16) * 16
+    S = torch.empty((N, lds), dtype=torch.float64, device=dev)
+    Hb = torch.empty((nz + 1, lds), dtype=torch.float64, device=dev)
+    delta = torch.empty(nz, dtype=torch.float64, device=dev)
+    losses = []
+    for _ in range(args.warmup):
+        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0)[0])
+    comm.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0)[0])
+    torch.cuda.synchronize(); comm.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    # accuracy (replicated work, tiny)
+    sol = z.cpu().numpy()
+    pts_l2 = float(np.sqrt(np.sum((u_true(Xd[:, 0], Xd[:, 1]) - sol) ** 2) / Nd))
+    coeff = t(np.concatenate([ALPHA * sol ** M_EXP - f, sol, g]))
+    ops.trsv(Theta, N, coeff, False); ops.trsv(Theta, N, coeff, True)
+    Xt = test_grid(60)
+    tXt = t(Xt)
+    ext = torch.empty(Xt.shape[0], dtype=torch.float64, device=dev)
+    ctx._chk(ctx.lib.gpk_extend(ctx.h, 0, 0, kp, tXt.data_ptr(), Xt.shape[0], tXd.data_ptr(), Nd, tXb.data_ptr(), Nb,
+                                coeff.data_ptr(), ext.data_ptr()))
+    torch.cuda.synchronize()
+    test_l2 = float(np.sqrt(np.sum((u_true(Xt[:, 0], Xt[:, 1]) - ext.cpu().numpy()) ** 2) / Xt.shape[0]))
+    out = None
+    if rank == 0:
+        out = {
+            'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
+            'value': args.steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
+                       'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
+                       'parallelism': f'panel-sharded Cholesky (block-cyclic columns, width {args.panel}, RCCL broadcast) + '
+                                      f'column-sharded TRSM + all-gather(S) + row-block-sharded SYRK over {world} rank(s)',
+                       'formulation': 'dense F1, nothing cached across steps'},
+            'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': args.warmup + args.steps,
+                         'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
+            'f1_tflops': f1_flops(N, nz) * args.steps / elapsed / 1e12,
+            'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step, F1 flops over all ranks)',
+                         'achieved': f1_flops(N, nz) * args.steps / elapsed / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS * world,
+                         'unit': 'TFLOP/s', 'frac': f1_flops(N, nz) * args.steps / elapsed / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+                         'traffic': None},
+            'cpu_baseline': None,
+        }
+    if use_pg:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', choices=['auto', 'c1', 'c2', 'c5'], default='auto')
+    ap.add_argument('--panel', type=int, default=512, help='panel width of the sharded Cholesky')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sharded-path', action='store_true', help='use the multi-rank schedule even with one rank')
+    args = ap.parse_args()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f'--gpus {args.gpus} needs {args.gpus} ranks: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} ...')
+    workload = args.workload if args.workload != 'auto' else ('c2' if args.gpus == 1 else 'c5')
+    if args.gpus > 1 or args.sharded_path or workload == 'c5':
+        out = run_sharded(args, workload)
+    else:
+        out = run_single(args, workload)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -56,6 +56,11 @@ int gpk_memcpy2d_d2d(gpk_handle h, void* dst, size_t dpitch, const void* src, si
 int gpk_timer_start(gpk_handle h);
 int gpk_timer_stop(gpk_handle h, double* host_ms);            /* synchronises */
 
+/* Per-phase HIP-event timing inside gpk_gn_step, recorded on the handle's stream (bench.py's roofline leg):
+ * host_ms4 = accumulated milliseconds of {TRSM phase, the SYRK launch, POTRF of H, TRSV + update} over *host_count steps. */
+int gpk_prof_enable(gpk_handle h, int on);                    /* also resets the accumulators */
+int gpk_prof_read(gpk_handle h, double* host_ms4, int* host_count);
+
 /* ---- Gram assembly: replaces Gram_matrix_assembly (src/Gram_matrice.py:11-187) plus the nugget of
  *      *.Gram_matrix (src/PDEs.py:56-73,250-269,391-409; src/InverseProblems.py:66-99) in one fused pass.
  *      kparams: Gaussian {sigma, unused}; anisotropic {sigma_t, sigma_x}.  Xd (Nd,2), Xb (Nb,2) row-major.
@@ -84,6 +89,9 @@ int gpk_symmetrize_lower(gpk_handle h, double* A, int n, int lda);   /* copy low
 /* jnp.linalg.solve(self.L, .) with the triangular factor (src/PDEs.py:86,97,143,161,288,306,429,450;
  * src/InverseProblems.py:118-119,145-146): B <- L^{-1} B (trans=0) or L^{-T} B (trans=1); B is n x nrhs. */
 int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+/* X <- X L^{-T} (X is m x n): the panel solve of the blocked Cholesky; exported for the multi-GPU panel-sharded
+ * factorisation, whose per-panel schedule lives in the host layer (gpk/sharded.py). */
+int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);
 /* B <- L^{-T} L^{-1} B (src/PDEs.py:205,347,502; src/InverseProblems.py:190,195) */
 int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 /* C <- alpha*op(A)*op(B) + beta*C; ta/tb = 1 means the operand is stored transposed (op(A) is m x k). */
@@ -116,6 +124,9 @@ int gpk_gn_dims(const gpk_gn_problem* host_prob, int* nz, int* s_rows);
  * host_loss_in = loss(z_in); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g. */
 int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double step_size,
                 double* S, int lds, double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);
+/* building blocks of gpk_gn_step for the column-sharded multi-GPU step: S <- [A(z) | F(z)] (no solve), y += alpha x */
+int gpk_gn_build(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* S, int lds);
+int gpk_axpy(gpk_handle h, int n, double alpha, const double* x, double* y);
 /* loss(z) (src/PDEs.py:82-87,278-289,418-430,138-147; src/InverseProblems.py:105-120); work: s_rows doubles. */
 int gpk_gn_loss(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* work, double* host_loss);
 /* Hessian_GN(z,z) and grad_loss(z) as the reference returns them (full symmetric H = 2 A^T Theta^{-1} A, g);

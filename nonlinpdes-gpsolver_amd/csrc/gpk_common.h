@@ -22,6 +22,11 @@ struct gpk_ctx {
     int num_cu = 256;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // column-group streams of the multi-RHS triangular solve
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // per-phase HIP-event timing of gpk_gn_step (bench.py roofline): 0 TRSM, 1 SYRK launch, 2 POTRF, 3 TRSV+update
+    bool prof = false;
+    hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double prof_ms[4] = {0, 0, 0, 0};
+    int prof_cnt = 0;
     std::string err;
 };
 

@@ -54,6 +54,7 @@ extern "C" int gpk_destroy(gpk_handle h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < 5; ++i) if (h->pev[i]) (void)hipEventDestroy(h->pev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -156,6 +157,22 @@ extern "C" int gpk_timer_stop(gpk_handle h, double* ms) {
     float f = 0.f;
     GPK_HIP(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
     *ms = (double)f;
+    return 0;
+}
+
+extern "C" int gpk_prof_enable(gpk_handle h, int on) {
+    if (!h) return GPK_ERR_ARG;
+    if (on && !h->pev[0]) for (int i = 0; i < 5; ++i) GPK_HIP(h, hipEventCreate(&h->pev[i]));
+    h->prof = on != 0;
+    for (int i = 0; i < 4; ++i) h->prof_ms[i] = 0.0;
+    h->prof_cnt = 0;
+    return 0;
+}
+
+extern "C" int gpk_prof_read(gpk_handle h, double* host_ms4, int* host_count) {
+    if (!h || !host_ms4 || !host_count) return GPK_ERR_ARG;
+    for (int i = 0; i < 4; ++i) host_ms4[i] = h->prof_ms[i];
+    *host_count = h->prof_cnt;
     return 0;
 }
 

@@ -483,6 +483,11 @@ extern "C" int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl
     return gpk_i_trsm_left_mt(h, trans != 0, L, n, ldl, B, nrhs, ldb);
 }
 
+extern "C" int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {
+    if (!h || !L || !X || n < 0 || m < 0 || ldl < n || ldx < n) return GPK_ERR_ARG;
+    return gpk_i_trsm_right_lt(h, L, n, ldl, X, m, ldx);
+}
+
 extern "C" int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
     GPK_TRY(gpk_trsm(h, 0, L, n, ldl, B, nrhs, ldb));
     return gpk_trsm(h, 1, L, n, ldl, B, nrhs, ldb);

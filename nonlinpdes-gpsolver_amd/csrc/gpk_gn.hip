@@ -155,16 +155,21 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
     return 0;
 }
 
+#define GPK_PROF_MARK(h, i) do { if ((h)->prof) GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } while (0)
+
 // S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered)
 int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, double* S, int lds,
                               double* Hb, int ldh, double alpha) {
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
+    GPK_PROF_MARK(h, 0);
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
     GPK_TRY(build(h, p, z, S, lds, d.nz, 1));
     for (int k = 0; k < d.ngroups; ++k)
         if (d.g[k].L) GPK_TRY(gpk_i_trsm_left_mt(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
+    GPK_PROF_MARK(h, 1);
     GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, S, lds, S, lds, 0.0, Hb, ldh, true));
+    GPK_PROF_MARK(h, 2);
     return 0;
 }
 
@@ -189,15 +194,25 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));                     // last row of the factor = (L_H^{-1} g/2)^T
+    GPK_PROF_MARK(h, 3);
     GPK_HIP(h, hipMemcpyAsync(delta, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, delta));
     axpy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, delta, z);
     GPK_LAUNCH_CHECK(h);
+    GPK_PROF_MARK(h, 4);
     int info = 0;
     double loss = 0.0;
     GPK_HIP(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipMemcpyAsync(&loss, d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->prof) {
+        for (int i = 0; i < 4; ++i) {
+            float ms = 0.f;
+            GPK_HIP(h, hipEventElapsedTime(&ms, h->pev[i], h->pev[i + 1]));
+            h->prof_ms[i] += (double)ms;
+        }
+        h->prof_cnt += 1;
+    }
     if (info == nz + 1) info = 0;          // the border pivot loss - y^T y is not part of H (may round below zero)
     if (host_info) *host_info = info;
     if (host_loss_in) *host_loss_in = loss;
@@ -226,6 +241,24 @@ extern "C" int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* p, const 
     GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, H, ldh, 2.0));   // H = 2 S^T S, g = 2 S^T w in the border row
     if (g) GPK_HIP(h, hipMemcpyAsync(g, H + (long)d.nz * ldh, (size_t)d.nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return gpk_symmetrize_lower(h, H, d.nz, ldh);
+}
+
+extern "C" int gpk_gn_build(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, int lds) {
+    if (!h || !z || !S) return GPK_ERR_ARG;
+    Dims d;
+    gpk_gn_problem q = *p;
+    if (gn_dims(&q, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
+    if (lds < d.nz + 1) return gpk_bad_arg(h, "gn: lds < nz+1");
+    GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
+    return build(h, &q, z, S, lds, d.nz, 1);
+}
+
+extern "C" int gpk_axpy(gpk_handle h, int n, double alpha, const double* x, double* y) {
+    if (!h || !x || !y || n < 0) return GPK_ERR_ARG;
+    if (n == 0) return 0;
+    axpy_kernel<<<gpk_ceil_div(n, 256), 256, 0, h->stream>>>(n, alpha, x, y);
+    GPK_LAUNCH_CHECK(h);
+    return 0;
 }
 
 extern "C" int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* p, const double* z, double* out) {

@@ -41,6 +41,8 @@ PROTOTYPES = {
     'gpk_memcpy2d_d2d': (_i, [_vp, _vp, _sz, _vp, _sz, _sz, _sz]),
     'gpk_timer_start': (_i, [_vp]),
     'gpk_timer_stop': (_i, [_vp, _pd]),
+    'gpk_prof_enable': (_i, [_vp, _i]),
+    'gpk_prof_read': (_i, [_vp, _pd, _pi]),
     'gpk_assemble': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _d, _i, _vp, _i, _pd]),
     'gpk_assemble_test': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _i]),
     'gpk_extend': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
@@ -48,11 +50,14 @@ PROTOTYPES = {
     'gpk_tril': (_i, [_vp, _vp, _i, _i]),
     'gpk_symmetrize_lower': (_i, [_vp, _vp, _i, _i]),
     'gpk_trsm': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
+    'gpk_trsm_right_lt': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     'gpk_potrs': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     'gpk_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i]),
     'gpk_syrk': (_i, [_vp, _i, _i, _d, _vp, _i, _d, _vp, _i, _i]),
     'gpk_gn_dims': (_i, [_pp, _pi, _pi]),
     'gpk_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _i, _vp, _pd, _pi]),
+    'gpk_gn_build': (_i, [_vp, _pp, _vp, _vp, _i]),
+    'gpk_axpy': (_i, [_vp, _i, _d, _vp, _vp]),
     'gpk_gn_loss': (_i, [_vp, _pp, _vp, _vp, _pd]),
     'gpk_gn_hessian_grad': (_i, [_vp, _pp, _vp, _vp, _i, _vp, _i, _vp]),
     'gpk_gn_measurement': (_i, [_vp, _pp, _vp, _vp]),

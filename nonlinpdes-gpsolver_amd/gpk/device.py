@@ -273,6 +273,16 @@ class Context:
         self.synchronize()
         return work.download()
 
+    # ---- per-phase timing of gn_step ----
+    def prof_enable(self, on=True):
+        self._chk(self.lib.gpk_prof_enable(self.h, int(on)))
+
+    def prof_read(self):
+        ms = (C.c_double * 4)()
+        n = C.c_int()
+        self._chk(self.lib.gpk_prof_read(self.h, ms, C.byref(n)))
+        return dict(steps=n.value, trsm_ms=ms[0], syrk_ms=ms[1], potrf_ms=ms[2], trsv_update_ms=ms[3])
+
     # ---- micro-benchmarks ----
     def ubench_mfma_f64(self, iters=20000):
         v = C.c_double()

@@ -1,0 +1,53 @@
+"""TEST DOUBLE for gpk.sharded.GpuBlockOps: the same block-operation interface on CPU torch tensors with numpy/scipy,
+so that the multi-process SCHEDULE of gpk/sharded.py (panel ownership, broadcasts, all-gathers) can be exercised with the
+gloo backend on a machine without GPUs.  Lives under tests/ only; the product has no CPU path."""
+import numpy as np
+from scipy.linalg import solve_triangular
+
+
+class NumpyBlockOps:
+    def __init__(self, oracle_system=None):
+        self.sys = oracle_system
+
+    def potrf(self, A, r0, n):
+        a = A.numpy()
+        blk = a[r0:r0 + n, r0:r0 + n]
+        try:
+            L = np.linalg.cholesky(np.tril(blk) + np.tril(blk, -1).T)
+        except np.linalg.LinAlgError:
+            blk[:] = np.nan
+            return 1
+        blk[np.tril_indices(n)] = L[np.tril_indices(n)]
+        return 0
+
+    def trsm_right(self, A, r0, n, row0, m):
+        a = A.numpy()
+        L = np.tril(a[r0:r0 + n, r0:r0 + n])
+        X = a[row0:row0 + m, r0:r0 + n]
+        X[:] = solve_triangular(L, X.T, lower=True, check_finite=False).T
+
+    def update_nt(self, Cm, cr, cc, m, n, k, A, ar, ac, B, br, bc):
+        Cm.numpy()[cr:cr + m, cc:cc + n] -= A.numpy()[ar:ar + m, ac:ac + k] @ B.numpy()[br:br + n, bc:bc + k].T
+
+    def gram_tn(self, Cm, cr, cc, m, n, k, A, ac, B, bc):
+        Cm.numpy()[cr:cr + m, cc:cc + n] = A.numpy()[:k, ac:ac + m].T @ B.numpy()[:k, bc:bc + n]
+
+    def trsm_left(self, L, n, B, c0, ncols, trans=False):
+        b = B.numpy()
+        b[:n, c0:c0 + ncols] = solve_triangular(np.tril(L.numpy()[:n, :n]), b[:n, c0:c0 + ncols], lower=True,
+                                                trans='T' if trans else 'N', check_finite=False)
+
+    def trsv(self, L, n, x, trans):
+        x.numpy()[:n] = solve_triangular(np.tril(L.numpy()[:n, :n]), x.numpy()[:n], lower=True, trans='T' if trans else 'N', check_finite=False)
+
+    def gn_build(self, prob_struct, z, S):
+        s = S.numpy()
+        s[:] = 0.0
+        zz = z.numpy()
+        A = self.sys.A(zz)[0]
+        F = self.sys.F(zz)[0]
+        s[:A.shape[0], :A.shape[1]] = A
+        s[:F.size, A.shape[1]] = F
+
+    def axpy(self, n, alpha, x, y):
+        y.numpy()[:n] += alpha * x.numpy()[:n]
