@@ -62,7 +62,12 @@ class GpuBlockOps:
         self.ctx = ctx
         self.lib = ctx.lib
         self.h = ctx.h
-        ctx._chk(self.lib.gpk_set_stream(self.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        # one explicit (non-default) torch stream carries everything: libgpk kernels, torch copies and, through
+        # torch.distributed's stream dependencies, the RCCL collectives.  (The legacy default stream has handle 0,
+        # which gpk_set_stream reads as "use the handle's own stream" -- that would race with torch.)
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        ctx._chk(self.lib.gpk_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
 
     @staticmethod
     def _p(T, r=0, c=0):
