@@ -37,6 +37,7 @@ WORKLOADS = {
     'c1': (900, 124, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=900 N_boundary=124 (BASELINE config 1)'),
     'c2': (4000, 400, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=4000 N_boundary=400 (BASELINE config 2)'),
     'c5': (16000, 2000, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=16000 N_boundary=2000 (BASELINE config 5)'),
+    'n10k': (10000, 1000, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=10000 N_boundary=1000 (north-star target size)'),
 }
 SIGMA, ALPHA, M_EXP = 0.2, 1.0, 3.0
 
@@ -301,7 +302,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['auto', 'c1', 'c2', 'c5'], default='auto')
+    ap.add_argument('--workload', choices=['auto', 'c1', 'c2', 'c5', 'n10k'], default='auto')
     ap.add_argument('--panel', type=int, default=512, help='panel width of the sharded Cholesky')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sharded-path', action='store_true', help='use the multi-rank schedule even with one rank')

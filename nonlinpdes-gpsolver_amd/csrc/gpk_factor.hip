@@ -116,57 +116,53 @@ __global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long 
     GPK_STAMP(3);
 }
 
-// ---- substitution with a <=64-wide diagonal block, one RHS column (or row of X) per lane ----------------------
+// ---- substitution with a <=64-wide diagonal block: 4 cooperating waves per 64 right-hand sides ------------------------
 // TRANS=false: L X = B;  TRANS=true: L^T X = B (index-reversed at load/store so the SAME forward algorithm runs).
 // ROWVEC=false: element (j, c) of B at B[j*ldb + c]  (left solve: lanes = consecutive columns, coalesced rows)
 // ROWVEC=true : element (j, c) of B at B[c*ldb + j]  (right solve X L^T = A viewed as L X^T = A^T; transposed via LDS)
-// X stays in LDS; 16 equations at a time are pulled into registers, solved against their 16x16 diagonal block, and
-// applied to the remaining equations in a loop (16 FMAs per iteration, coefficients by broadcast ds_read_b128).
+// Lane = right-hand side in every wave.  Staging is ONE round trip to memory (each wave fetches 16 rows of L and 16 of
+// B; a dependent load costs ~3 us here because the operands were just written by another kernel).  The solve walks four
+// 16-equation blocks: every wave solves the 16x16 diagonal block redundantly in registers (no hand-off), then the
+// remaining equations are updated a quarter per wave (16 FMAs per broadcast ds_read_b128 pair), one barrier per block.
+// A single wave doing all of it was LDS-issue bound at ~25 us per launch; ~130 + 63 such launches sit on the critical
+// path of every Gauss-Newton step.
 template <bool TRANS, bool ROWVEC>
-__global__ __launch_bounds__(64) void trsm_base_kernel(const double* __restrict__ L, long ldl, int nb,
-                                                       double* __restrict__ B, long ldb, int ncols, int dbg) {
+__global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict__ L, long ldl, int nb,
+                                                        double* __restrict__ B, long ldb, int ncols, int dbg) {
     GPK_STAMP(4);
     __shared__ __attribute__((aligned(16))) double Ws[NB * WS];      // Ws[a*WS + b]: coefficient of x_b in equation a
-    __shared__ double Xs[NB * XS];                                   // Xs[a*XS + lane]
+    __shared__ double Xs[NB * XS];                                   // right-hand sides, Xs[a*XS + lane]
+    __shared__ double Ys[NB * XS];                                   // solved values
     __shared__ double rds[NB];                                       // 1 / diagonal
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blockIdx.x * NB;
     const int c = c0 + lane;
     const int lc = min(lane, nb - 1);
-    const int rl = TRANS ? nb - 1 - lane : lane;                     // mapped index of `lane` (valid when lane < nb)
     const int nr = ROWVEC ? min(NB, ncols - c0) : nb;                // rows of the B tile as stored in memory
     const int cc = min(c, ncols - 1);
-    // Two round trips to memory in total (a dependent global load costs ~3 us here: the operands were just written by
-    // another XCD): each half issues 32 rows of L and 32 rows of B together, the LDS zero-fill hides under the first.
+    // index map: equations are reversed for the transposed solve (only the first nb indices; the rest are padding)
+    auto rho = [nb](int i) { return (TRANS && i < nb) ? nb - 1 - i : i; };
+    {
+        double tl[RB], tx[RB];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int r0 = half * LB;
-        double tl[LB], tx[LB];
+        for (int u = 0; u < RB; ++u) tl[u] = L[(long)min(wave * RB + u, nb - 1) * ldl + lc];
 #pragma unroll
-        for (int u = 0; u < LB; ++u) tl[u] = L[(long)min(r0 + u, nb - 1) * ldl + lc];
-#pragma unroll
-        for (int u = 0; u < LB; ++u)
-            tx[u] = ROWVEC ? B[(long)(c0 + min(r0 + u, nr - 1)) * ldb + lc] : B[(long)min(r0 + u, nb - 1) * ldb + cc];
-        if (half == 0) {
-            for (int a = 0; a < NB; ++a) { Ws[a * WS + lane] = 0.0; Xs[a * XS + lane] = 0.0; }
-            if (lane < WS - NB) for (int a = 0; a < NB; ++a) Ws[a * WS + NB + lane] = 0.0;
-            rds[lane] = 1.0;
-            __syncthreads();
-            GPK_STAMP(5);
+        for (int u = 0; u < RB; ++u) {
+            const int r = wave * RB + u;
+            tx[u] = ROWVEC ? B[(long)(c0 + min(r, nr - 1)) * ldb + lc] : B[(long)min(r, nb - 1) * ldb + cc];
         }
+        GPK_STAMP(5);
 #pragma unroll
-        for (int u = 0; u < LB; ++u) {
-            const int r = r0 + u;
-            if (r < nb && lane < nb) {
-                const int rr = TRANS ? nb - 1 - r : r;
-                // L[r][lane], lane < r: forward -> x_lane in equation r; transposed -> x_r in equation lane
-                if (lane < r) { if (TRANS) Ws[rl * WS + rr] = tl[u]; else Ws[rr * WS + rl] = tl[u]; }
-                if (lane == r) rds[rr] = 1.0 / tl[u];
-            }
-            if (ROWVEC) { if (r < nr && lane < nb) Xs[rl * XS + r] = tx[u]; }
-            else        { if (r < nb) Xs[(TRANS ? nb - 1 - r : r) * XS + lane] = tx[u]; }
+        for (int u = 0; u < RB; ++u) {                               // every (r, lane) pair writes exactly one entry
+            const int r = wave * RB + u;
+            const bool valid = (r < nb) && (lane < nb);
+            const double v = (valid && lane < r) ? tl[u] : 0.0;      // strictly lower part of L, zero elsewhere
+            if (TRANS) Ws[rho(lane) * WS + rho(r)] = v;              // L[r][lane]: x_r in equation lane
+            else       Ws[r * WS + lane] = v;                        //             x_lane in equation r
+            if (lane == r) rds[rho(r)] = valid ? 1.0 / tl[u] : 1.0;
+            if (ROWVEC) Xs[rho(lane) * XS + r] = (r < nr && lane < nb) ? tx[u] : 0.0;
+            else        Xs[rho(r) * XS + lane] = (r < nb && c < ncols) ? tx[u] : 0.0;
         }
-        if (half == 0) GPK_STAMP(6);
     }
     __syncthreads();
     GPK_STAMP(7);
@@ -177,15 +173,18 @@ __global__ __launch_bounds__(64) void trsm_base_kernel(const double* __restrict_
 #pragma unroll
         for (int i = 0; i < RB; ++i) x[i] = Xs[(r0 + i) * XS + lane];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {                               // 16x16 diagonal block, right-looking: the
-            const double xi = x[i] * rds[r0 + i];                    // updates of one step are independent FMAs
+        for (int i = 0; i < RB; ++i) {                               // 16x16 diagonal block (every wave, redundantly)
+            const double xi = x[i] * rds[r0 + i];
             x[i] = xi;
 #pragma unroll
             for (int j = i + 1; j < RB; ++j) x[j] = fma(-Ws[(r0 + j) * WS + r0 + i], xi, x[j]);
         }
+        if (wave == 0) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) Xs[(r0 + i) * XS + lane] = x[i];
-        for (int r = r0 + RB; r < NB; r += 4) {                      // apply to the remaining equations, 4 at a time
+            for (int i = 0; i < RB; ++i) Ys[(r0 + i) * XS + lane] = x[i];
+        }
+        // remaining equations: groups of 4 rows, dealt round-robin to the waves
+        for (int r = r0 + RB + 4 * wave; r < NB; r += 16) {
             const double* __restrict__ wr = Ws + r * WS + r0;
             double acc0 = Xs[r * XS + lane], acc1 = Xs[(r + 1) * XS + lane];
             double acc2 = Xs[(r + 2) * XS + lane], acc3 = Xs[(r + 3) * XS + lane];
@@ -199,18 +198,25 @@ __global__ __launch_bounds__(64) void trsm_base_kernel(const double* __restrict_
             Xs[r * XS + lane] = acc0; Xs[(r + 1) * XS + lane] = acc1;
             Xs[(r + 2) * XS + lane] = acc2; Xs[(r + 3) * XS + lane] = acc3;
         }
+        __syncthreads();
     }
-    __syncthreads();
     GPK_STAMP(8);
+    // equations past the last solved block are padding; solved values leave through Ys, 16 rows per wave
     if (ROWVEC) {
         if (lane < nb) {
-#pragma unroll 8
-            for (int r = 0; r < nr; ++r) B[(long)(c0 + r) * ldb + lane] = Xs[rl * XS + r];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = wave * RB + u;
+                if (r < nr) B[(long)(c0 + r) * ldb + lane] = Ys[rho(lane) * XS + r];
+            }
         }
     } else {
         if (c < ncols) {
-#pragma unroll 8
-            for (int r = 0; r < nb; ++r) B[(long)r * ldb + c] = Xs[(TRANS ? nb - 1 - r : r) * XS + lane];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = wave * RB + u;
+                if (r < nb) B[(long)r * ldb + c] = Ys[rho(r) * XS + lane];
+            }
         }
     }
     GPK_STAMP(9);
@@ -309,8 +315,8 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
     if (n <= 0 || nrhs <= 0) return 0;
     if (n <= NB) {
         dim3 grid(gpk_ceil_div(nrhs, NB));
-        if (trans) trsm_base_kernel<true, false><<<grid, 64, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
-        else       trsm_base_kernel<false, false><<<grid, 64, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
+        if (trans) trsm_base_kernel<true, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
+        else       trsm_base_kernel<false, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -374,7 +380,7 @@ int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {
     if (n <= 0 || m <= 0) return 0;
     if (n <= NB) {
-        trsm_base_kernel<false, true><<<gpk_ceil_div(m, NB), 64, 0, h->stream>>>(L, ldl, n, X, ldx, m, g_dbg);
+        trsm_base_kernel<false, true><<<gpk_ceil_div(m, NB), 256, 0, h->stream>>>(L, ldl, n, X, ldx, m, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -406,7 +412,7 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
             const int below = n - (j0 + nb);
             if (below > 0) {
                 double* Abj = A + (long)(j0 + nb) * lda + j0;
-                trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 64, 0, h->stream>>>(Ajj, lda, nb, Abj, lda, below, g_dbg);
+                trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, Abj, lda, below, g_dbg);
                 const int pc = k0 + ob - (j0 + nb);                   // remaining columns of this outer panel
                 if (pc > 0) {
                     // A[j0+nb:, j0+nb : k0+ob] -= L[j0+nb:, j] * L[j0+nb : k0+ob, j]^T   (rows above the diagonal

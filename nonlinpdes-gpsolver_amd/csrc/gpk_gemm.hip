@@ -198,6 +198,99 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
 }
 
+// ---- rank-<=64 updates: everything in flight at once -----------------------------------------------------------------
+// The K = 64 updates of the TRSM recursion and of the POTRF panels (C -= A B, ~130 launches per Gauss-Newton step at
+// C2) spend their time in dependent memory round trips, not in MFMAs: with the slab-by-slab pipeline above a 64x64
+// tile pays one ~3 us round trip per 16-deep slab plus one for the read-modify-write of C.  Here all four slabs of A
+// and B and the C tile are requested before anything is waited for: one round trip, one barrier, 64 MFMAs per wave.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, WM = 32, WN = 32, TM = 2, TN = 2, NK = 4;
+    constexpr int A_SZ = TA ? BK * (BM + 16) : BM * (BK + 2);
+    constexpr int B_SZ = TB ? BN * (BK + 2) : BK * (BN + 16);
+    __shared__ __attribute__((aligned(16))) double smem[NK * (A_SZ + B_SZ)];
+    double* const As = smem;
+    double* const Bs = smem + NK * A_SZ;
+    int tm, tn;
+    map_tile(g, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int li = lane & 15, lk = lane >> 4;
+
+    d2 ra[NK][BM * BK / 512], rb[NK][BN * BK / 512];
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kt * BK, g.K, g.vecA, ra[kt]);
+        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kt * BK, g.K, g.vecB, rb[kt]);
+    }
+    // accumulators start from C (sign folded in: the only combinations routed here are beta = 0, or beta = 1 with
+    // alpha = +-1, for which acc = C/alpha is exact)
+    d4 acc[TM][TN];
+    const bool has_c = (g.beta != 0.0);
+    const double cs = has_c ? g.beta / g.alpha : 0.0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(m0 + wm0 + 16 * i + lk + 4 * r, g.M - 1);
+                const int col = min(n0 + wn0 + 16 * j + li, g.N - 1);
+                acc[i][j][r] = has_c ? cs * g.C[(long)row * g.ldc + col] : 0.0;
+            }
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        store_tile<!TA, BM>(As + kt * A_SZ, ra[kt]);
+        store_tile<TB, BN>(Bs + kt * B_SZ, rb[kt]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        const double* __restrict__ as = As + kt * A_SZ;
+        const double* __restrict__ bs = Bs + kt * B_SZ;
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            double a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = lds_at<!TA, BM>(as, wm0 + 16 * i + li, 4 * ks + lk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = lds_at<TB, BN>(bs, wn0 + 16 * j + li, 4 * ks + lk);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm0 + 16 * i + lk + 4 * r;
+            if (row >= g.M) continue;
+            double* crow = g.C + (long)row * g.ldc;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn0 + 16 * j + li;
+                if (col < g.N) crow[col] = g.alpha * acc[i][j][r];
+            }
+        }
+}
+
+int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
+    g.ntm = gpk_ceil_div(g.M, 64);
+    g.ntn = gpk_ceil_div(g.N, 64);
+    g.ntiles = g.ntm * g.ntn;
+    dim3 grid(g.ntiles), block(256);
+    if (!ta && !tb) gemm_k64_kernel<false, false><<<grid, block, 0, h->stream>>>(g);
+    else if (!ta && tb) gemm_k64_kernel<false, true><<<grid, block, 0, h->stream>>>(g);
+    else if (ta && !tb) gemm_k64_kernel<true, false><<<grid, block, 0, h->stream>>>(g);
+    else gemm_k64_kernel<true, true><<<grid, block, 0, h->stream>>>(g);
+    GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.ntm = gpk_ceil_div(g.M, BM);
@@ -247,6 +340,9 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.lower_only = lower_only ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
+    if (k <= 64 && !lower_only && g_force_cfg == 0 &&
+        (beta == 0.0 || (beta == 1.0 && (alpha == 1.0 || alpha == -1.0))))
+        return launch_k64(h, ta, tb, g);
     // big tiles once they fill the chip (256 CUs x 2 resident workgroups); small tiles keep more CUs busy otherwise
     const long tm = gpk_ceil_div(m, 128), tn = gpk_ceil_div(n, 128);
     const long big_tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
