@@ -48,9 +48,11 @@ int gpk_bad_arg(gpk_handle h, const char* what);
 // ---- internal (stream-ordered, no host sync) building blocks -------------------------------------------------
 // C <- alpha*op(A)*op(B) + beta*C.  lower_only: skip tiles strictly above the diagonal (square C).
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
-               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only);
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0);
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+// forward solve exploiting leading zeros of the right-hand side columns (see gpk_factor.hip)
+int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead, int row0);
 // same, right-hand sides split into independent column groups that run on concurrent streams
 int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);

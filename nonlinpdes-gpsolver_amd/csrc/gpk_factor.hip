@@ -336,6 +336,35 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
     return 0;
 }
 
+// Forward solve L X = B when column c of B (c < lead) is known to be zero in the rows above (lead - 1 - c): the
+// Gauss-Newton right-hand side [A(z) | F] with the unknowns stored in REVERSE order has exactly this shape (column j of
+// A is zero above row j).  For the sub-problem on rows [row0, row0 + n) only the columns
+// c >= lead - (row0 + n) can be non-zero, so every recursive solve, update GEMM and diagonal solve is restricted to
+// that contiguous range (rounded down to 64 columns to keep tiles and vector loads aligned).  Columns >= lead are dense.
+int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead, int row0) {
+    if (n <= 0 || nrhs <= 0) return 0;
+    int clo = lead - (row0 + n);
+    clo = clo > 0 ? (clo / NB) * NB : 0;
+    if (clo >= nrhs) return 0;
+    if (n <= NB) {
+        trsm_base_kernel<false, false><<<gpk_ceil_div(nrhs - clo, NB), 256, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, g_dbg);
+        GPK_LAUNCH_CHECK(h);
+        return 0;
+    }
+    const int n1 = split(n), n2 = n - n1;
+    const double* L21 = L + (long)n1 * ldl;
+    double* B2 = B + (long)n1 * ldb;
+    GPK_TRY(gpk_i_trsm_left_lz(h, L, n1, ldl, B, nrhs, ldb, lead, row0));
+    int c1 = lead - (row0 + n1);                                     // X[rows of part 1] is zero left of this column
+    c1 = c1 > 0 ? (c1 / NB) * NB : 0;
+    if (c1 < nrhs) {                                                 // X1[k][c] is zero for row0 + k < lead-1-c: late K start per tile
+        const int lz = lead - row0 - c1;
+        GPK_TRY(gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, B + c1, ldb, 1.0, B2 + c1, ldb, false, lz > 0 ? lz : 0));
+    }
+    GPK_TRY(gpk_i_trsm_left_lz(h, L21 + n1, n2, ldl, B2, nrhs, ldb, lead, row0 + n1));
+    return 0;
+}
+
 // The 64-row diagonal solves of a multi-RHS TRSM keep only nrhs/64 waves busy and sit on the critical path between
 // the GEMM updates.  Column groups of the right-hand side are independent, so they are issued on separate streams:
 // while one group runs a (latency-bound) diagonal solve the other groups' GEMMs fill the chip.

@@ -36,6 +36,9 @@ struct GemmArgs {
     const double* B; long ldb;
     double* C; long ldc;
     int lower_only;
+    int lead;          // operand B (stored [k][n]) has column n zero for k < lead-1-n: the tile with columns [n0, n0+BN)
+                       // gets no contribution from k < lead - (n0 + BN), so its K loop starts there.  (SYRK S^T S,
+                       // lower tiles: the A tile's columns are further right, i.e. non-zero even earlier.)
     int vecA, vecB;
     int ntm, ntn, ntiles;
 };
@@ -99,7 +102,10 @@ __device__ __forceinline__ void map_tile(const GemmArgs& g, int& tm, int& tn) {
     const int b = blockIdx.x;
     const int xcd = b & 7, idx = b >> 3;
     const int q = nwg >> 3, r = nwg & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // leading-zero operands: tiles further right run a longer K loop; hand the long ones out first so that the short
+    // ones fill the tail of the launch
+    if (g.lead > 0) logical = nwg - 1 - logical;
     if (g.lower_only) {
         int i = (int)((sqrt(8.0 * (double)logical + 1.0) - 1.0) * 0.5);
         while ((long)(i + 1) * (i + 2) / 2 <= logical) ++i;
@@ -143,13 +149,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
     d2 ra[BM * BK / 512], rb[BN * BK / 512];
     const int nk = (g.K + BK - 1) / BK;
-    load_tile<!TA, BM>(g.A, g.lda, m0, g.M, 0, g.K, g.vecA, ra);
-    load_tile<TB, BN>(g.B, g.ldb, n0, g.N, 0, g.K, g.vecB, rb);
-    store_tile<!TA, BM>(As, ra);
-    store_tile<TB, BN>(Bs, rb);
+    int kt0 = 0;
+    if (g.lead > 0) {                                                 // both operands are zero above this row (tm >= tn)
+        const int z = g.lead - (n0 + BN);
+        kt0 = z > 0 ? z / BK : 0;
+        if (kt0 > nk) kt0 = nk;
+    }
+    load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kt0 * BK, g.K, g.vecA, ra);
+    load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kt0 * BK, g.K, g.vecB, rb);
+    store_tile<!TA, BM>(As + (kt0 & 1) * A_SZ, ra);
+    store_tile<TB, BN>(Bs + (kt0 & 1) * B_SZ, rb);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, g.vecA, ra);
@@ -330,7 +342,7 @@ extern "C" int gpk_debug_set(int key, int value) {
 }
 
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
-               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only) {
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead) {
     if (m <= 0 || n <= 0) return 0;
     if (k < 0 || !A || !B || !C) return gpk_bad_arg(h, "gemm: sizes/pointers");
     if (lower_only && m != n) return gpk_bad_arg(h, "gemm: lower_only needs a square C");
@@ -338,6 +350,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.M = m; g.N = n; g.K = k; g.alpha = alpha; g.beta = beta;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.lower_only = lower_only ? 1 : 0;
+    g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
     if (k <= 64 && !lower_only && g_force_cfg == 0 &&

@@ -50,9 +50,13 @@ struct BuildArgs {
     double p0, p1, lam;
     const double* f; const double* gb; const double* data; const double* z;
     double* S; long lds; int fcol; int write_A;
+    int rev;           // store unknown j in column nz-1-j (gn_step of the elliptic system: leading-zero structure)
+    int nz;
 };
 
-__device__ __forceinline__ void putA(const BuildArgs& a, int r, int c, double v) { if (a.write_A) a.S[(long)r * a.lds + c] = v; }
+__device__ __forceinline__ void putA(const BuildArgs& a, int r, int c, double v) {
+    if (a.write_A) a.S[(long)r * a.lds + (a.rev ? a.nz - 1 - c : c)] = v;
+}
 __device__ __forceinline__ void putF(const BuildArgs& a, int r, double v) { a.S[(long)r * a.lds + a.fcol] = v; }
 
 // one thread per collocation index: writes the few non-zeros of A(z) and the entries of F(z) it owns
@@ -131,13 +135,25 @@ __global__ void axpy_kernel(int n, double alpha, const double* __restrict__ x, d
     if (i < n) y[i] += alpha * x[i];
 }
 
+// y[j] += alpha * x[n-1-j]
+__global__ void axpy_rev_kernel(int n, double alpha, const double* __restrict__ x, double* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] += alpha * x[n - 1 - i];
+}
+
+__global__ void reverse_copy_kernel(int n, const double* __restrict__ x, double* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = x[n - 1 - i];
+}
+
 __global__ void scale_kernel(int n, double alpha, double* __restrict__ x) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) x[i] *= alpha;
 }
 
-int build(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, long lds, int fcol, int write_A) {
+int build(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, long lds, int fcol, int write_A, int rev = 0) {
     BuildArgs a;
+    a.rev = rev; a.nz = fcol;
     a.system = p->system; a.Nd = p->Nd; a.Nb = p->Nb; a.Ndata = p->Ndata;
     a.p0 = p->p0; a.p1 = p->p1; a.lam = p->pen_lambda;
     a.f = p->rhs_f; a.gb = p->bdy_g; a.data = p->data_u; a.z = z;
@@ -157,18 +173,24 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
 
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } while (0)
 
-// S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered)
+// S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered).
+// rev != 0 (elliptic system only): unknown j is stored in column nz-1-j; column c < nz of [A | F] is then zero above row
+// nz-1-c, which the solve and the SYRK exploit (about a third of the TRSM flops and a quarter of the SYRK flops).
 int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, double* S, int lds,
-                              double* Hb, int ldh, double alpha) {
+                              double* Hb, int ldh, double alpha, int rev) {
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
     GPK_PROF_MARK(h, 0);
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
-    GPK_TRY(build(h, p, z, S, lds, d.nz, 1));
-    for (int k = 0; k < d.ngroups; ++k)
-        if (d.g[k].L) GPK_TRY(gpk_i_trsm_left_mt(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
+    GPK_TRY(build(h, p, z, S, lds, d.nz, 1, rev));
+    if (rev) {
+        GPK_TRY(gpk_i_trsm_left_lz(h, d.g[0].L, d.g[0].n, d.g[0].ldl, S, nc, lds, d.nz, 0));
+    } else {
+        for (int k = 0; k < d.ngroups; ++k)
+            if (d.g[k].L) GPK_TRY(gpk_i_trsm_left_mt(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
+    }
     GPK_PROF_MARK(h, 1);
-    GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, S, lds, S, lds, 0.0, Hb, ldh, true));
+    GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, S, lds, S, lds, 0.0, Hb, ldh, true, rev ? d.nz : 0));
     GPK_PROF_MARK(h, 2);
     return 0;
 }
@@ -189,15 +211,22 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     Dims d;
     GPK_TRY(check_prob(h, p, d));
     const int nz = d.nz;
-    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0));
+    const int rev = (p->system == GPK_GN_ELLIPTIC) ? 1 : 0;
+    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev));
     double* d_loss = h->d_scalars;
     GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));                     // last row of the factor = (L_H^{-1} g/2)^T
     GPK_PROF_MARK(h, 3);
-    GPK_HIP(h, hipMemcpyAsync(delta, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, delta));
-    axpy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, delta, z);
+    double* dl = rev ? S : delta;                                    // scratch for the (reversed-order) solution: S is free now
+    GPK_HIP(h, hipMemcpyAsync(dl, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, dl));
+    if (rev) {
+        reverse_copy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, dl, delta);
+        axpy_rev_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, dl, z);
+    } else {
+        axpy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, delta, z);
+    }
     GPK_LAUNCH_CHECK(h);
     GPK_PROF_MARK(h, 4);
     int info = 0;
@@ -238,7 +267,7 @@ extern "C" int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* p, const 
     if (!h || !z || !S || !H) return GPK_ERR_ARG;
     Dims d;
     GPK_TRY(check_prob(h, p, d));
-    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, H, ldh, 2.0));   // H = 2 S^T S, g = 2 S^T w in the border row
+    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, H, ldh, 2.0, 0));   // H = 2 S^T S, g = 2 S^T w in the border row
     if (g) GPK_HIP(h, hipMemcpyAsync(g, H + (long)d.nz * ldh, (size_t)d.nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     return gpk_symmetrize_lower(h, H, d.nz, ldh);
 }
