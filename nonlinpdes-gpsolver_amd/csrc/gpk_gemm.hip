@@ -105,7 +105,8 @@ __device__ __forceinline__ void map_tile(const GemmArgs& g, int& tm, int& tn) {
     int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     // leading-zero operands: tiles further right run a longer K loop; hand the long ones out first so that the short
     // ones fill the tail of the launch
-    if (g.lead > 0) logical = nwg - 1 - logical;
+    // (no per-XCD chunking then: contiguous chunks of a work ramp would load the XCDs unevenly; round-robin keeps them level)
+    if (g.lead > 0) logical = nwg - 1 - b;
     if (g.lower_only) {
         int i = (int)((sqrt(8.0 * (double)logical + 1.0) - 1.0) * 0.5);
         while ((long)(i + 1) * (i + 2) / 2 <= logical) ++i;
