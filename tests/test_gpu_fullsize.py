@@ -1,0 +1,115 @@
+"""Full-size (BASELINE config 2: N_domain=4000, N_boundary=400 -> Theta of order 8400) checks on the GPU through
+size-independent properties -- the oracle is too slow to be the checker here (prompt (3)):
+  * Theta: exactly symmetric; every diagonal entry equals the analytic value (+ nugget); a random sample of entries and
+    a random block agree with the oracle's closed forms
+  * Cholesky: info = 0 and || L L^T - Theta || <= 1e-14 ||Theta||, computed on the device
+  * triangular solve with n_z+1 right-hand sides: || L X - B || small; the leading-zero aware path used by gn_step
+    agrees with the plain one (same operation, different schedule)
+  * Gauss-Newton: the loss decreases monotonically after the first steps and the solution reaches the manufactured truth
+    to < 1e-6 (reference L2-error definition), i.e. the 'L2 error' half of the metric at full size
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O
+
+ND, NB_, SIGMA = 4000, 400, 0.2
+
+
+@pytest.fixture(scope='module')
+def setup():
+    import gpk
+    ctx = gpk.Context(0)
+    np.random.seed(0)
+    from src.sample_points import sampled_pts_rdm
+    Xd, Xb = sampled_pts_rdm(ND, NB_, np.array([[0, 1], [0, 1]]))
+    yield ctx, Xd, Xb
+    ctx.close()
+
+
+def test_theta_properties_full_size(setup):
+    ctx, Xd, Xb = setup
+    nug = 1e-9
+    T, ratios = ctx.assemble('Nonlinear_elliptic', 'Gaussian', SIGMA, Xd, Xb, nug, 'adaptive')
+    A = T.download()
+    N = 2 * ND + NB_
+    assert A.shape == (N, N)
+    assert np.array_equal(A, A.T)
+    p = 1.0 / SIGMA ** 2
+    np.testing.assert_allclose(np.diag(A)[:ND], 8 * p * p + nug * ratios[0], rtol=1e-14)
+    np.testing.assert_allclose(np.diag(A)[ND:], 1.0 + nug, rtol=1e-15)
+    assert ratios[0] == pytest.approx(ND * 8 * p * p / (ND + NB_), rel=1e-14)
+    rng = np.random.RandomState(1)
+    Xdb = np.concatenate([Xd, Xb])
+    # random entries of each block against the closed forms
+    i = rng.randint(0, ND, 400); j = rng.randint(0, ND, 400)
+    want = O.deriv_kernel('Delta_x_Delta_y_kappa', Xd[i, 0], Xd[i, 1], Xd[j, 0], Xd[j, 1], 'Gaussian', SIGMA)
+    mask = i != j
+    assert np.max(np.abs(A[i, j] - want)[mask]) <= 4e-15 * 8 * p * p
+    j2 = rng.randint(0, ND + NB_, 400)
+    want = O.deriv_kernel('Delta_x_kappa', Xd[i, 0], Xd[i, 1], Xdb[j2, 0], Xdb[j2, 1], 'Gaussian', SIGMA)
+    assert np.max(np.abs(A[i, ND + j2] - want)) <= 4e-15 * 2 * p
+    # one contiguous block straddling the domain/boundary seam
+    r0 = ND + ND - 50
+    blk = O.deriv_kernel('kappa', Xdb[ND - 50:ND + 50, None, 0], Xdb[ND - 50:ND + 50, None, 1], Xdb[None, ND - 50:ND + 50, 0],
+                         Xdb[None, ND - 50:ND + 50, 1], 'Gaussian', SIGMA)
+    got = A[r0:r0 + 100, r0:r0 + 100].copy()
+    got[np.arange(100), np.arange(100)] -= nug
+    assert np.max(np.abs(got - blk)) <= 4e-15
+
+
+def test_cholesky_and_solves_full_size(setup):
+    ctx, Xd, Xb = setup
+    N = 2 * ND + NB_
+    T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', SIGMA, Xd, Xb, 1e-9, 'adaptive')
+    L = T.clone()
+    assert ctx.potrf(L) == 0
+    ctx.tril(L)
+    R = T.clone()                                               # R <- Theta - L L^T on the device
+    ctx.gemm(0, 1, N, N, N, -1.0, L, L, 1.0, R)
+    res = R.download()
+    theta_norm = np.linalg.norm(T.download())
+    assert np.linalg.norm(res) <= 1e-14 * theta_norm
+    # multi-RHS solve
+    rng = np.random.RandomState(2)
+    nrhs = ND + 1
+    B = rng.normal(size=(N, nrhs))
+    X = ctx.array(B)
+    ctx.trsm(L, X)
+    Rb = ctx.array(B)
+    ctx.gemm(0, 0, N, nrhs, N, -1.0, L, X, 1.0, Rb)             # B - L X
+    Lh = L.download()
+    assert np.linalg.norm(Rb.download()) <= 1e-13 * np.linalg.norm(Lh) * np.linalg.norm(X.download())
+
+
+def test_gauss_newton_reaches_truth_full_size(setup):
+    import gpk
+    ctx, Xd, Xb = setup
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', SIGMA, Xd, Xb, 1e-12, 'adaptive')
+    assert ctx.potrf(T) == 0
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', ND, NB_, f, g, T, p0=1.0, p1=3.0)
+    rng = np.random.RandomState(3)
+    z0 = rng.normal(size=ND)
+    z = ctx.array(z0)
+    # the structured step (gn_step: reversed unknown order, structural zeros skipped) against the plain Hessian/gradient
+    # entry point (natural order, dense) on the same iterate: delta must agree
+    H, grad = ctx.gn_hessian_grad(prob, ctx.array(z0))
+    hist = [ctx.gn_step(prob, z)[0]]
+    _, _, delta, _ = prob.workspace()
+    d_dev = delta.download()
+    z1 = z.download()
+    np.testing.assert_allclose(z1, z0 - d_dev, rtol=0, atol=1e-9 * np.abs(z0).max())
+    res = H @ d_dev - grad                                       # H delta = g  (both carry the reference's factor 2)
+    assert np.linalg.norm(res) <= 1e-6 * np.linalg.norm(grad)
+    for _ in range(7):
+        loss, info = ctx.gn_step(prob, z)
+        assert info == 0
+        hist.append(loss)
+    hist.append(ctx.gn_loss(prob, z))
+    assert all(b <= a * (1 + 1e-9) for a, b in zip(hist[3:], hist[4:]))          # monotone once past the first steps
+    sol = z.download()
+    err = O.elliptic_truth(Xd[:, 0], Xd[:, 1]) - sol
+    assert np.sqrt(np.sum(err ** 2) / ND) < 1e-6
