@@ -54,19 +54,21 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane /* wave-unif
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base, int dbg) {
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base, int dbg) {
     GPK_STAMP(0);
     __shared__ double As[NB * XS];                                  // As[r*XS + c]
     __shared__ __attribute__((aligned(16))) double Ps[NB * RB];     // factored panel, Ps[r*16 + i] = L[r][r0+i]
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = min(lane, n - 1);
-    {                                                               // coalesced rows, all 64 loads in flight at once
-        double t[NB];
+    {                                                               // one round trip: each wave fetches 16 rows
+        double t[RB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u) t[u] = A[(long)min(u, n - 1) * lda + cl];
+        for (int u = 0; u < RB; ++u) t[u] = A[(long)min(wave * RB + u, n - 1) * lda + cl];
 #pragma unroll
-        for (int u = 0; u < NB; ++u)
-            As[u * XS + lane] = (u < n && lane < n) ? t[u] : ((u == lane) ? 1.0 : 0.0);   // identity padding
+        for (int u = 0; u < RB; ++u) {
+            const int r = wave * RB + u;
+            As[r * XS + lane] = (r < n && lane < n) ? t[u] : ((r == lane) ? 1.0 : 0.0);   // identity padding
+        }
     }
     __syncthreads();
     GPK_STAMP(1);
@@ -74,6 +76,8 @@ __global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long 
     const int nblk = (n + RB - 1) / RB;
     for (int kb = 0; kb < nblk; ++kb) {
         const int r0 = kb * RB;
+        // Every wave holds all 64 rows (lane = row) and factors the 16-column panel redundantly: the four waves sit on
+        // four different SIMDs, so this costs no time and saves a hand-off; the trailing update is then split 4 ways.
         double a[RB];
 #pragma unroll
         for (int i = 0; i < RB; ++i) a[i] = As[lane * XS + r0 + i];
@@ -84,17 +88,19 @@ __global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long 
             const double rs = rsqrt(d);                              // 1/sqrt(d), then one Newton step for sqrt(d)
             const double s0 = d * rs;
             const double sq = fma(fma(-s0, s0, d), 0.5 * rs, s0);
-            const double lij = (lane == r0 + j) ? sq : a[j] * rs;    // LAPACK dpotf2 also scales by the reciprocal
-            a[j] = lij;
-#pragma unroll
+            const double lij = a[j] * rs;                            // LAPACK dpotf2 also scales by the reciprocal
+            a[j] = (lane == r0 + j) ? sq : lij;                      // sqrt(d) only lands on the diagonal: off the
+#pragma unroll                                                       // dependency chain of the updates below
             for (int k = j + 1; k < RB; ++k) a[k] -= lij * bcast_lane(lij, r0 + k);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) { As[lane * XS + r0 + i] = a[i]; Ps[lane * RB + i] = a[i]; }
-        __syncthreads();
-        for (int c = r0 + RB; c < NB; c += 4) {                      // trailing update of row `lane`, 4 columns at a
-            const double* __restrict__ pc = Ps + c * RB;             // time: a single wave needs the ILP (a serial
-            double acc0 = As[lane * XS + c], acc1 = As[lane * XS + c + 1];   // 16-FMA chain costs ~10 cycles per link)
+        for (int i = 0; i < RB; ++i) {
+            Ps[lane * RB + i] = a[i];                                // identical values from every wave (benign)
+            if (wave == 0) As[lane * XS + r0 + i] = a[i];
+        }
+        for (int c = r0 + RB + 4 * wave; c < NB; c += 16) {          // trailing update of row `lane`: 4 columns per
+            const double* __restrict__ pc = Ps + c * RB;             // trip, column groups dealt round-robin to waves
+            double acc0 = As[lane * XS + c], acc1 = As[lane * XS + c + 1];
             double acc2 = As[lane * XS + c + 2], acc3 = As[lane * XS + c + 3];
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
@@ -109,10 +115,12 @@ __global__ __launch_bounds__(64) void potf2_kernel(double* __restrict__ A, long 
         __syncthreads();
     }
     GPK_STAMP(2);
-#pragma unroll 8
-    for (int r = 0; r < n; ++r)
-        if (lane <= r) A[(long)r * lda + lane] = As[r * XS + lane];
-    if (bad && bad <= n && lane == 0) atomicCAS(info, 0, pivot_base + bad);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+        const int r = wave * RB + u;
+        if (r < n && lane <= r) A[(long)r * lda + lane] = As[r * XS + lane];
+    }
+    if (bad && bad <= n && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     GPK_STAMP(3);
 }
 
@@ -437,7 +445,7 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
         for (int j0 = k0; j0 < k0 + ob; j0 += NB) {
             const int nb = (k0 + ob - j0 < NB) ? k0 + ob - j0 : NB;
             double* Ajj = A + (long)j0 * lda + j0;
-            potf2_kernel<<<1, 64, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
+            potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
             const int below = n - (j0 + nb);
             if (below > 0) {
                 double* Abj = A + (long)(j0 + nb) * lda + j0;
