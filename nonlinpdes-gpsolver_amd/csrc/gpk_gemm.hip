@@ -127,6 +127,7 @@ __device__ __forceinline__ void map_tile(const GemmArgs& g, int& tm, int& tn) {
 template <int BM, int BN, int WM, int WN, bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr bool PF2 = (BM * BN <= 64 * 64);                      // prefetch depth 2 for the small-tile configuration
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
     constexpr int A_SZ = TA ? BK * (BM + 16) : BM * (BK + 2);
@@ -148,7 +149,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    d2 ra[BM * BK / 512], rb[BN * BK / 512];
     const int nk = (g.K + BK - 1) / BK;
     int kt0 = 0;
     if (g.lead > 0) {                                                 // both operands are zero above this row (tm >= tn)
@@ -156,20 +156,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         kt0 = z > 0 ? z / BK : 0;
         if (kt0 > nk) kt0 = nk;
     }
-    load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kt0 * BK, g.K, g.vecA, ra);
-    load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kt0 * BK, g.K, g.vecB, rb);
-    store_tile<!TA, BM>(As + (kt0 & 1) * A_SZ, ra);
-    store_tile<TB, BN>(Bs + (kt0 & 1) * B_SZ, rb);
-    __syncthreads();
-
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, g.vecA, ra);
-            load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, g.vecB, rb);
-        }
-        const double* __restrict__ as = As + cur * A_SZ;
-        const double* __restrict__ bs = Bs + cur * B_SZ;
+    auto compute = [&](int buf) {
+        const double* __restrict__ as = As + buf * A_SZ;
+        const double* __restrict__ bs = Bs + buf * B_SZ;
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             double a[TM], b[TN];
@@ -183,11 +172,86 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) {
-            store_tile<!TA, BM>(As + (cur ^ 1) * A_SZ, ra);
-            store_tile<TB, BN>(Bs + (cur ^ 1) * B_SZ, rb);
+    };
+    constexpr int NA = BM * BK / 512, NB = BN * BK / 512;
+    int kdone = kt0;                                                  // slabs [kt0, kdone) are accumulated
+    if (PF2) {
+        // Interior tiles of aligned operands, full slabs only: two slabs in flight with STRAIGHT-LINE unguarded 16-byte
+        // loads (slab index clamped instead of branched around), so that the compiler's s_waitcnt before the LDS store
+        // of slab t+1 can leave the four loads of slab t+2 outstanding (vmcnt(4)); with the loads behind branches it
+        // fell back to vmcnt(0), i.e. to one slab in flight.  Ablation on 8192^3 (tools/gemm_exp_probe.py): 62.5 TF/s
+        // with the feed, 73.9 without -- the feed latency, not the MFMA pipe or LDS, is what is left to hide.
+        // Rows of A / columns of B beyond the matrix edge only feed rows / columns of C that are never stored, so edge
+        // tiles need no masking in m and n, only in-bounds addresses (clamped below; for an m-contiguous operand the last
+        // 16-byte pair may read the padding element at column X, which exists because the leading dimension is even).
+        const bool fast = g.vecA && g.vecB;
+        const int nkf = fast ? g.K / BK : kt0;                        // full slabs
+        if (nkf > kt0) {
+            const int t = threadIdx.x;
+            const double* pa[NA]; const double* pb[NB];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int lin = t + 256 * i;
+                pa[i] = !TA ? g.A + (long)min(m0 + lin / (BK / 2), g.M - 1) * g.lda + (lin % (BK / 2)) * 2
+                            : g.A + (long)(lin / (BM / 2)) * g.lda + min(m0 + (lin % (BM / 2)) * 2, (g.M - 1) & ~1);
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int lin = t + 256 * i;
+                pb[i] = TB ? g.B + (long)min(n0 + lin / (BK / 2), g.N - 1) * g.ldb + (lin % (BK / 2)) * 2
+                           : g.B + (long)(lin / (BN / 2)) * g.ldb + min(n0 + (lin % (BN / 2)) * 2, (g.N - 1) & ~1);
+            }
+            const long sa = !TA ? (long)BK : (long)BK * g.lda, sb = TB ? (long)BK : (long)BK * g.ldb;
+            d2 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+            auto load = [&](int kt, d2 (&ra)[NA], d2 (&rb)[NB]) {
+                const int kc = min(kt, nkf - 1);                      // past the end: re-read the last slab (never used)
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const d2*>(pa[i] + kc * sa);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const d2*>(pb[i] + kc * sb);
+            };
+            auto store = [&](int buf, const d2 (&ra)[NA], const d2 (&rb)[NB]) {
+                store_tile<!TA, BM>(As + buf * A_SZ, ra);
+                store_tile<TB, BN>(Bs + buf * B_SZ, rb);
+            };
+            load(kt0, ra0, rb0);
+            load(kt0 + 1, ra1, rb1);
+            store(kt0 & 1, ra0, rb0);
+            __syncthreads();
+            for (int kt = kt0; kt < nkf; kt += 2) {
+                load(kt + 2, ra0, rb0);                               // registers 0 are free (slab kt sits in LDS)
+                compute(kt & 1);
+                store((kt + 1) & 1, ra1, rb1);
+                __syncthreads();
+                if (kt + 1 >= nkf) break;
+                load(kt + 3, ra1, rb1);
+                compute((kt + 1) & 1);
+                store(kt & 1, ra0, rb0);
+                __syncthreads();
+            }
+            kdone = nkf;
         }
+    }
+    if (kdone < nk) {                                                 // edge tiles, unaligned operands, the partial slab
+        d2 ra[NA], rb[NB];
+        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kdone * BK, g.K, g.vecA, ra);
+        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kdone * BK, g.K, g.vecB, rb);
+        store_tile<!TA, BM>(As + (kdone & 1) * A_SZ, ra);
+        store_tile<TB, BN>(Bs + (kdone & 1) * B_SZ, rb);
         __syncthreads();
+        for (int kt = kdone; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, g.vecA, ra);
+                load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, g.vecB, rb);
+            }
+            compute(cur);
+            if (kt + 1 < nk) {
+                store_tile<!TA, BM>(As + (cur ^ 1) * A_SZ, ra);
+                store_tile<TB, BN>(Bs + (cur ^ 1) * B_SZ, rb);
+            }
+            __syncthreads();
+        }
     }
 
     const bool has_beta = (g.beta != 0.0);
