@@ -230,6 +230,134 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
     GPK_STAMP(9);
 }
 
+// ---- forward substitution with a <=256-wide diagonal block, fused: one launch per 256-row strip ------------------------
+// L X = B for a diagonal block of up to SB = 256 rows; one workgroup (4 waves) owns SNC = 32 right-hand-side columns and
+// keeps its 256 x 32 slice of B in LDS for the whole solve.  The strip is walked in 16 blocks of 16 equations:
+//   solve   : 16 x 16 triangular block by true substitution, lane = column, coefficients broadcast from LDS;
+//   update  : the row tiles below get  X_t -= L[t][s] X_s  on the matrix cores (v_mfma_f64_16x16x4_f64, K = 16), row
+//             tiles dealt round-robin to the four waves; the wave that updates tile s+1 solves block s+1 right away,
+//             so the other waves' updates of step s overlap the (latency-bound) substitution of step s+1;
+//   one barrier per step; the L tiles of step s+1 are fetched (clamped, branch-free) while step s runs.
+// This replaces, per 256 rows, four 64-row trsm_base launches (12.4 us each), two K=64, one K=128 GEMM launch and their
+// launch gaps: those levels of the recursion keep at most 126 workgroups busy anyway and cost 3.1 of the 6.5 ms the
+// Gauss-Newton TRSM took at N = 8400 (profiles/r01_*).  No inverse of a diagonal block is ever formed.
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int SB = 256, SNC = 32, SXS = SNC + 16;                    // LDS row stride 48: rows k, k+1 are 128 B apart mod 256
+
+__global__ __launch_bounds__(256) void trsm_strip_kernel(const double* __restrict__ L, long ldl, int n,
+                                                         double* __restrict__ B, long ldb, int ncols) {
+    __shared__ __attribute__((aligned(16))) double Xs[SB * SXS];
+    __shared__ double Ld[SB * 16];                                   // Ld[256 blk + 16 i + j] = L[16 blk + j][16 blk + i], j > i
+    __shared__ double rd[SB];                                        // 1 / diagonal
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int c0 = blockIdx.x * SNC;
+    const int nsteps = (n + 15) >> 4;
+
+    // the L tiles this wave needs in update step s: rows of tiles t = first(s) + 4k (k = 0..3), columns 16 s .. 16 s + 15,
+    // MFMA A-operand layout (lane holds L[16 t + li][16 s + 4 q + lk], q = 0..3); tiles past the end re-read the last row
+    auto first_tile = [wave](int s) { return s + 1 + ((wave - (s + 1)) & 3); };
+    auto load_a = [&](int s, double (&a)[4][4]) {
+        const int sc = min(s, nsteps - 1);
+        const int t0 = first_tile(sc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = min(16 * (t0 + 4 * k) + li, n - 1);
+            const double* __restrict__ p = L + (long)row * ldl + 16 * sc + lk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[k][q] = p[min(4 * q, n - 1 - 16 * sc - lk)];
+        }
+    };
+    double a0[4][4], a1[4][4];
+    load_a(0, a0);
+    {   // stage the slice of B (rows >= n and columns >= ncols as zeros) and the sixteen 16x16 diagonal blocks
+        const int col = tid & 31, rb = tid >> 5;
+        const int cc = min(c0 + col, ncols - 1);
+        double v[SB / 8];
+#pragma unroll
+        for (int i = 0; i < SB / 8; ++i) v[i] = B[(long)min(rb + 8 * i, n - 1) * ldb + cc];
+        const int blk = tid >> 4, j = tid & 15;
+        const int grow = min(16 * blk + j, n - 1);
+        double d[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = L[(long)grow * ldl + min(16 * blk + i, n - 1)];
+#pragma unroll
+        for (int i = 0; i < SB / 8; ++i) Xs[(rb + 8 * i) * SXS + col] = (rb + 8 * i < n && c0 + col < ncols) ? v[i] : 0.0;
+        const bool rv = 16 * blk + j < n;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Ld[256 * blk + 16 * i + j] = (rv && i < j) ? d[i] : 0.0;
+        double dj = 1.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (i == j) dj = d[i];
+        rd[16 * blk + j] = rv ? 1.0 / dj : 1.0;
+    }
+    __syncthreads();
+
+    auto solve = [&](int s) {                                        // lanes 32..63 mirror lanes 0..31
+        const int col = lane & 31;
+        double x[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = Xs[(16 * s + j) * SXS + col];
+        const double* __restrict__ ld = Ld + 256 * s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double xi = x[i] * rd[16 * s + i];
+            x[i] = xi;
+#pragma unroll
+            for (int j = i + 1; j < 16; ++j) x[j] = fma(-ld[16 * i + j], xi, x[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) Xs[(16 * s + j) * SXS + col] = x[j];
+    };
+    auto step = [&](int s, const double (&a)[4][4]) {
+        double nb[2][4];                                             // -X_s in MFMA B-operand layout: B[k = 4q + lk][n = li]
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nb[c][q] = -Xs[(16 * s + 4 * q + lk) * SXS + 16 * c + li];
+        const int t0 = first_tile(s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + 4 * k;
+            if (t < nsteps) {
+                d4 acc[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[c][r] = Xs[(16 * t + lk + 4 * r) * SXS + 16 * c + li];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k][q], nb[c][q], acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Xs[(16 * t + lk + 4 * r) * SXS + 16 * c + li] = acc[c][r];
+                if (k == 0 && t == s + 1) solve(t);                  // this wave owns the next diagonal block
+            }
+        }
+        __syncthreads();
+    };
+
+    if (wave == 0) solve(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps - 1; s += 2) {
+        load_a(s + 1, a1);
+        step(s, a0);
+        if (s + 1 >= nsteps - 1) break;
+        load_a(s + 2, a0);
+        step(s + 1, a1);
+    }
+    {
+        const int col = tid & 31, rb = tid >> 5;
+        if (c0 + col < ncols) {
+#pragma unroll
+            for (int i = 0; i < SB / 8; ++i)
+                if (rb + 8 * i < n) B[(long)(rb + 8 * i) * ldb + c0 + col] = Xs[(rb + 8 * i) * SXS + col];
+        }
+    }
+}
+
 // ---- single-vector triangular solve: 64-wide diagonal block by one wave (lane = equation) ---------------------
 template <bool TRANS>
 __global__ __launch_bounds__(64) void trsv_diag_kernel(const double* __restrict__ L, long ldl, int nb, double* __restrict__ x) {
@@ -307,9 +435,15 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
 
 int g_dbg = 0;
 int g_mt_trsm = 0;
+int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
-inline int split(int n) {
-    // first part: about half, a multiple of 128 when there is room (keeps GEMM operands aligned and tiles full)
+inline int split(int n, int base = NB) {
+    // first part: about half, a multiple of 128 when there is room (keeps GEMM operands aligned and tiles full);
+    // with 256-row strip solves at the bottom of the recursion, a multiple of the strip height
+    if (base == SB) {
+        const int n1 = ((n / 2 + SB - 1) / SB) * SB;
+        return n1 < n ? n1 : SB;
+    }
     const int q = (n > 256) ? 128 : NB;
     int n1 = ((n / 2 + q - 1) / q) * q;
     if (n1 >= n) n1 = ((n / 2 + NB - 1) / NB) * NB;
@@ -321,6 +455,11 @@ inline int split(int n) {
 
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
     if (n <= 0 || nrhs <= 0) return 0;
+    if (!trans && g_strip && n <= SB) {
+        trsm_strip_kernel<<<gpk_ceil_div(nrhs, SNC), 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs);
+        GPK_LAUNCH_CHECK(h);
+        return 0;
+    }
     if (n <= NB) {
         dim3 grid(gpk_ceil_div(nrhs, NB));
         if (trans) trsm_base_kernel<true, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
@@ -328,7 +467,7 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    const int n1 = split(n), n2 = n - n1;
+    const int n1 = split(n, (!trans && g_strip) ? SB : NB), n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     const double* L22 = L21 + n1;
     double* B2 = B + (long)n1 * ldb;
@@ -354,12 +493,17 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
     int clo = lead - (row0 + n);
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
+    if (g_strip && n <= SB) {
+        trsm_strip_kernel<<<gpk_ceil_div(nrhs - clo, SNC), 256, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo);
+        GPK_LAUNCH_CHECK(h);
+        return 0;
+    }
     if (n <= NB) {
         trsm_base_kernel<false, false><<<gpk_ceil_div(nrhs - clo, NB), 256, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    const int n1 = split(n), n2 = n - n1;
+    const int n1 = split(n, g_strip ? SB : NB), n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     double* B2 = B + (long)n1 * ldb;
     GPK_TRY(gpk_i_trsm_left_lz(h, L, n1, ldl, B, nrhs, ldb, lead, row0));
@@ -501,6 +645,7 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------
 extern "C" int gpk_debug_set_mt_trsm(int v) { g_mt_trsm = v; return 0; }
+extern "C" int gpk_debug_set_strip(int v) { g_strip = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

@@ -399,10 +399,12 @@ __global__ void tril_kernel(double* A, int n, long lda) {
 static int g_force_cfg = 0;          // development aid (gpk_debug_set key 0): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
 
 extern "C" int gpk_debug_set_mt_trsm(int v);
+extern "C" int gpk_debug_set_strip(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
     if (key == 2) return gpk_debug_set_mt_trsm(value);
+    if (key == 3) return gpk_debug_set_strip(value);
     return GPK_ERR_ARG;
 }
 
