@@ -28,6 +28,62 @@ __global__ __launch_bounds__(256) void hbm_write_kernel(double* __restrict__ p, 
     const size_t stride = (size_t)gridDim.x * 256;
     for (; i < n; i += stride) p[i] = v;
 }
+
+// single-wave latency/issue probes (cycles per operation by s_memtime): the diagonal-block kernels are bound by these
+__global__ __launch_bounds__(64) void lat_probe_kernel(int mode, double* out, const double* gbuf, int stride) {
+    __shared__ double lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = (double)((i + 1) & 1023);
+    __syncthreads();
+    double x0 = 1.0 + threadIdx.x * 1e-9, x1 = x0, x2 = x0, x3 = x0, x4 = x0, x5 = x0, x6 = x0, x7 = x0;
+    const double m = 1.0 - 1e-12, c = 1e-13;
+    constexpr int N = 512;
+    long t0 = 0, t1 = 0;
+    if (mode == 0) {                                                 // dependent v_fma_f64 chain
+        t0 = clock64();
+#pragma unroll 16
+        for (int i = 0; i < N; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x0) : "v"(m), "v"(c));
+        t1 = clock64();
+    } else if (mode == 1) {                                          // 8 independent chains: issue rate
+        t0 = clock64();
+#pragma unroll 4
+        for (int i = 0; i < N / 8; ++i)
+            asm volatile("v_fma_f64 %0, %0, %8, %9\n\tv_fma_f64 %1, %1, %8, %9\n\tv_fma_f64 %2, %2, %8, %9\n\tv_fma_f64 %3, %3, %8, %9\n\t"
+                         "v_fma_f64 %4, %4, %8, %9\n\tv_fma_f64 %5, %5, %8, %9\n\tv_fma_f64 %6, %6, %8, %9\n\tv_fma_f64 %7, %7, %8, %9"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(m), "v"(c));
+        t1 = clock64();
+    } else if (mode == 2) {                                          // dependent LDS reads (pointer chase): latency
+        int idx = threadIdx.x;
+        t0 = clock64();
+#pragma unroll 16
+        for (int i = 0; i < N; ++i) idx = (int)lds[idx & 1023];
+        t1 = clock64();
+        x0 = idx;
+    } else if (mode == 3) {                                          // independent broadcast ds_read_b64: issue rate
+        t0 = clock64();
+#pragma unroll 16
+        for (int i = 0; i < N; ++i) { x0 += lds[i]; }
+        t1 = clock64();
+    } else if (mode == 4) {                                          // dependent MFMA chain
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 acc = {0, 0, 0, 0};
+        t0 = clock64();
+#pragma unroll 16
+        for (int i = 0; i < N; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(m), "v"(c));
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        t1 = clock64();
+        x0 = acc[0];
+    }
+    else if (mode == 5 || mode == 6) {                              // dependent global loads: 5 = one line per wave, 6 = 16 lines
+        long idx = (mode == 5) ? 0 : (long)(threadIdx.x & 15) * stride + (threadIdx.x >> 4);
+        t0 = clock64();
+#pragma unroll 8
+        for (int i = 0; i < N; ++i) { const double v = gbuf[idx]; idx += (long)v; }   // buffer holds zeros
+        t1 = clock64();
+        x0 = (double)idx;
+    }
+    const double s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+    if (threadIdx.x == 0) { out[0] = (double)(t1 - t0) / N; out[1] = s; }
+}
 }  // namespace
 
 extern "C" int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops) {
@@ -57,5 +113,19 @@ extern "C" int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, doubl
     GPK_TRY(gpk_timer_stop(h, &ms));
     GPK_HIP(h, hipFree(buf));
     *host_gbps = (double)n * sizeof(double) * iters / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+extern "C" int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_per_op) {
+    if (!h || !host_cycles_per_op) return GPK_ERR_ARG;
+    double* gbuf = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&gbuf, 16 * 1056 * sizeof(double)));
+    GPK_HIP(h, hipMemsetAsync(gbuf, 0, 16 * 1056 * sizeof(double), h->stream));
+    lat_probe_kernel<<<1, 64, 0, h->stream>>>(mode, h->d_scalars + 8, gbuf, 1056);
+    lat_probe_kernel<<<1, 64, 0, h->stream>>>(mode, h->d_scalars + 8, gbuf, 1056);
+    GPK_LAUNCH_CHECK(h);
+    GPK_HIP(h, hipMemcpyAsync(host_cycles_per_op, h->d_scalars + 8, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    if (gbuf) GPK_HIP(h, hipFree(gbuf));
     return 0;
 }

@@ -231,131 +231,167 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
 }
 
 // ---- forward substitution with a <=256-wide diagonal block, fused: one launch per 256-row strip ------------------------
-// L X = B for a diagonal block of up to SB = 256 rows; one workgroup (4 waves) owns SNC = 32 right-hand-side columns and
+// L X = B for a diagonal block of up to SB = 256 rows; one workgroup (8 waves) owns SNC = 32 right-hand-side columns and
 // keeps its 256 x 32 slice of B in LDS for the whole solve.  The strip is walked in 16 blocks of 16 equations:
-//   solve   : 16 x 16 triangular block by true substitution, lane = column, coefficients broadcast from LDS;
-//   update  : the row tiles below get  X_t -= L[t][s] X_s  on the matrix cores (v_mfma_f64_16x16x4_f64, K = 16), row
-//             tiles dealt round-robin to the four waves; the wave that updates tile s+1 solves block s+1 right away,
-//             so the other waves' updates of step s overlap the (latency-bound) substitution of step s+1;
+//   solve   : 16 x 16 triangular block by true substitution, lane = column, coefficients wave-uniform (scalar loads);
+//   update  : the row tiles below get  X_t -= L[t][s] X_s  on the matrix cores (v_mfma_f64_16x16x4_f64, K = 16); the
+//             wave that updates tile s+1 solves block s+1 right away and does nothing else in that step, the other seven
+//             waves share the tiles further down, so their updates overlap the (latency-bound) substitution;
 //   one barrier per step; the L tiles of step s+1 are fetched (clamped, branch-free) while step s runs.
 // This replaces, per 256 rows, four 64-row trsm_base launches (12.4 us each), two K=64, one K=128 GEMM launch and their
 // launch gaps: those levels of the recursion keep at most 126 workgroups busy anyway and cost 3.1 of the 6.5 ms the
 // Gauss-Newton TRSM took at N = 8400 (profiles/r01_*).  No inverse of a diagonal block is ever formed.
+// Measured (tools/strip_probe.py, n = 256, 4001 columns): 44 us per launch = ~5 us staging + 15 steps x ~2.4 us
+// (owner's tile update ~0.7 us, then its substitution ~0.8 us, both latency chains of one wave) + ~1 us store.
 typedef double d4 __attribute__((ext_vector_type(4)));
-constexpr int SB = 256, SNC = 32, SXS = SNC + 16;                    // LDS row stride 48: rows k, k+1 are 128 B apart mod 256
+constexpr int SB = 256, SNC = 32, SNT = 512;
+constexpr int SXS = SNC + 16;                                        // LDS row stride 48: rows k, k+1 are 128 B apart mod 256
+constexpr int SAS = 18;                                              // L tile row stride: operand reads hit 32 distinct bank pairs
 
-__global__ __launch_bounds__(256) void trsm_strip_kernel(const double* __restrict__ L, long ldl, int n,
-                                                         double* __restrict__ B, long ldb, int ncols) {
+__global__ __launch_bounds__(SNT) void trsm_strip_kernel(const double* __restrict__ L, long ldl, int n,
+                                                         double* __restrict__ B, long ldb, int ncols, int dbg) {
+    GPK_STAMP(10);
     __shared__ __attribute__((aligned(16))) double Xs[SB * SXS];
-    __shared__ double Ld[SB * 16];                                   // Ld[256 blk + 16 i + j] = L[16 blk + j][16 blk + i], j > i
     __shared__ double rd[SB];                                        // 1 / diagonal
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) double At[(SNT / 64) * 2 * 16 * SAS];   // per wave: two 16x16 tiles of L
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: role tests become scalar branches
     const int li = lane & 15, lk = lane >> 4;
     const int c0 = blockIdx.x * SNC;
-    const int nsteps = (n + 15) >> 4;
+    const int nsteps = n >> 4;                                       // the host guarantees n % 16 == 0
 
-    // the L tiles this wave needs in update step s: rows of tiles t = first(s) + 4k (k = 0..3), columns 16 s .. 16 s + 15,
-    // MFMA A-operand layout (lane holds L[16 t + li][16 s + 4 q + lk], q = 0..3); tiles past the end re-read the last row
-    auto first_tile = [wave](int s) { return s + 1 + ((wave - (s + 1)) & 3); };
-    auto load_a = [&](int s, double (&a)[4][4]) {
+    // Roles in update step s (X_s solved, tiles t > s to be updated with it): wave (s+1) mod 8 owns tile s+1 and solves
+    // block s+1 right after updating it; the other seven waves take tiles s+1+j and s+8+j (j = their distance from the
+    // owner).  tiles_of() returns the two tiles of this wave (>= nsteps: none).
+    auto tiles_of = [wave](int s, int& t0, int& t1) {
+        const int j = (wave - (s + 1)) & 7;                          // 0 = owner
+        t0 = s + 1 + j;
+        t1 = j == 0 ? SB : s + 8 + j;
+    };
+    // L tiles of the next step: fetched with coalesced 16-byte loads (8 lanes per 128-byte tile row; the MFMA A-operand
+    // layout itself puts adjacent lanes on different rows = 64 separate line accesses per load, which made the eight
+    // waves' tile loads alone cost ~3000 cycles per step), kept in registers for one step, then passed through a
+    // wave-private LDS tile to reach the operand layout.  Tile indices are clamped, so the loads are branch-free.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    auto load_a = [&](int s, d2 (&a)[2][2]) {
         const int sc = min(s, nsteps - 1);
-        const int t0 = first_tile(sc);
+        int t[2];
+        tiles_of(sc, t[0], t[1]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = min(16 * (t0 + 4 * k) + li, n - 1);
-            const double* __restrict__ p = L + (long)row * ldl + 16 * sc + lk;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[k][q] = p[min(4 * q, n - 1 - 16 * sc - lk)];
+        for (int k = 0; k < 2; ++k) {
+            const double* __restrict__ p = L + (long)(16 * min(t[k], nsteps - 1) + (lane >> 3)) * ldl + 16 * sc + 2 * (lane & 7);
+            a[k][0] = *reinterpret_cast<const d2*>(p);
+            a[k][1] = *reinterpret_cast<const d2*>(p + 8 * ldl);
         }
     };
-    double a0[4][4], a1[4][4];
+    double* const at = At + wave * (2 * 16 * SAS);
+    auto to_operand = [&](const d2 (&a)[2][2], double (&op)[2][4]) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double* __restrict__ w = at + k * 16 * SAS + (lane >> 3) * SAS + 2 * (lane & 7);
+            *reinterpret_cast<d2*>(w) = a[k][0];
+            *reinterpret_cast<d2*>(w + 8 * SAS) = a[k][1];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) op[k][q] = at[k * 16 * SAS + li * SAS + 4 * q + lk];
+    };
+    d2 a0[2][2], a1[2][2];
     load_a(0, a0);
-    {   // stage the slice of B (rows >= n and columns >= ncols as zeros) and the sixteen 16x16 diagonal blocks
+    {   // stage the slice of B (columns >= ncols as zeros) and the reciprocal diagonal: one round trip to memory
         const int col = tid & 31, rb = tid >> 5;
         const int cc = min(c0 + col, ncols - 1);
-        double v[SB / 8];
+        double v[SB / 16];
 #pragma unroll
-        for (int i = 0; i < SB / 8; ++i) v[i] = B[(long)min(rb + 8 * i, n - 1) * ldb + cc];
-        const int blk = tid >> 4, j = tid & 15;
-        const int grow = min(16 * blk + j, n - 1);
-        double d[16];
+        for (int i = 0; i < SB / 16; ++i) v[i] = B[(long)min(rb + 16 * i, n - 1) * ldb + cc];
+        const double dg = L[(long)min(tid, n - 1) * (ldl + 1)];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) d[i] = L[(long)grow * ldl + min(16 * blk + i, n - 1)];
-#pragma unroll
-        for (int i = 0; i < SB / 8; ++i) Xs[(rb + 8 * i) * SXS + col] = (rb + 8 * i < n && c0 + col < ncols) ? v[i] : 0.0;
-        const bool rv = 16 * blk + j < n;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Ld[256 * blk + 16 * i + j] = (rv && i < j) ? d[i] : 0.0;
-        double dj = 1.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) if (i == j) dj = d[i];
-        rd[16 * blk + j] = rv ? 1.0 / dj : 1.0;
+        for (int i = 0; i < SB / 16; ++i) Xs[(rb + 16 * i) * SXS + col] = (rb + 16 * i < n && c0 + col < ncols) ? v[i] : 0.0;
+        if (tid < SB) rd[tid] = 1.0 / dg;
     }
     __syncthreads();
+    GPK_STAMP(11);
 
-    auto solve = [&](int s) {                                        // lanes 32..63 mirror lanes 0..31
+    // 16 x 16 substitution, lane = column (lanes 32..63 mirror lanes 0..31).  The coefficients are wave-uniform and come
+    // straight from L through the scalar cache (s_load into SGPRs, an SGPR operand per v_fma_f64): broadcasting them
+    // from LDS made the 120 ds_reads the bottleneck of the whole kernel (2900 cycles per block, round 1 stamps).
+    auto solve = [&](int s) {
         const int col = lane & 31;
+        double* __restrict__ xp = Xs + 16 * s * SXS + col;
+        const double* __restrict__ Ls = L + (long)(16 * s) * (ldl + 1);
         double x[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x[j] = Xs[(16 * s + j) * SXS + col];
-        const double* __restrict__ ld = Ld + 256 * s;
+        for (int j = 0; j < 16; ++j) x[j] = xp[j * SXS];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const double xi = x[i] * rd[16 * s + i];
-            x[i] = xi;
+        for (int j = 0; j < 16; ++j) {
+            double e = x[j], o = 0.0;
 #pragma unroll
-            for (int j = i + 1; j < 16; ++j) x[j] = fma(-ld[16 * i + j], xi, x[j]);
+            for (int i = 0; i < j; ++i) {
+                if (i & 1) o = fma(-Ls[(long)j * ldl + i], x[i], o);
+                else       e = fma(-Ls[(long)j * ldl + i], x[i], e);
+            }
+            x[j] = (e + o) * rd[16 * s + j];
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) Xs[(16 * s + j) * SXS + col] = x[j];
+        for (int j = 0; j < 16; ++j) xp[j * SXS] = x[j];
     };
-    auto step = [&](int s, const double (&a)[4][4]) {
-        double nb[2][4];                                             // -X_s in MFMA B-operand layout: B[k = 4q + lk][n = li]
+    auto update = [&](int s, int t, const double (&a)[4], const double (&nb)[2][4]) {
+        double* __restrict__ xt = Xs + (16 * t + lk) * SXS + li;
+        d4 acc[2];
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) nb[c][q] = -Xs[(16 * s + 4 * q + lk) * SXS + 16 * c + li];
-        const int t0 = first_tile(s);
+            for (int r = 0; r < 4; ++r) acc[c][r] = xt[4 * r * SXS + 16 * c];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = t0 + 4 * k;
-            if (t < nsteps) {
-                d4 acc[2];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nb[c][q], acc[c], 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[c][r] = Xs[(16 * t + lk + 4 * r) * SXS + 16 * c + li];
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 4; ++r) xt[4 * r * SXS + 16 * c] = acc[c][r];
+    };
+    auto step = [&](int s, const d2 (&ar)[2][2]) {
+        int t0, t1;
+        tiles_of(s, t0, t1);
+        if (t0 < nsteps) {
+            double a[2][4];
+            to_operand(ar, a);
+            double nb[2][4];                                         // -X_s in MFMA B-operand layout: B[k = 4q + lk][n = li]
+            const double* __restrict__ xs = Xs + (16 * s + lk) * SXS + li;
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k][q], nb[c][q], acc[c], 0, 0, 0);
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Xs[(16 * t + lk + 4 * r) * SXS + 16 * c + li] = acc[c][r];
-                if (k == 0 && t == s + 1) solve(t);                  // this wave owns the next diagonal block
-            }
+                for (int q = 0; q < 4; ++q) nb[c][q] = -xs[4 * q * SXS + 16 * c];
+            update(s, t0, a[0], nb);
+            if (t0 == s + 1) solve(t0);                              // this wave owns the next diagonal block
+            else if (t1 < nsteps) update(s, t1, a[1], nb);
         }
         __syncthreads();
     };
 
     if (wave == 0) solve(0);
     __syncthreads();
+    GPK_STAMP(12);
     for (int s = 0; s < nsteps - 1; s += 2) {
         load_a(s + 1, a1);
         step(s, a0);
+        if (s == 0) GPK_STAMP(13);
         if (s + 1 >= nsteps - 1) break;
         load_a(s + 2, a0);
         step(s + 1, a1);
     }
+    GPK_STAMP(14);
     {
         const int col = tid & 31, rb = tid >> 5;
         if (c0 + col < ncols) {
 #pragma unroll
-            for (int i = 0; i < SB / 8; ++i)
-                if (rb + 8 * i < n) B[(long)(rb + 8 * i) * ldb + c0 + col] = Xs[(rb + 8 * i) * SXS + col];
+            for (int i = 0; i < SB / 16; ++i)
+                if (rb + 16 * i < n) B[(long)(rb + 16 * i) * ldb + c0 + col] = Xs[(rb + 16 * i) * SXS + col];
         }
     }
+    GPK_STAMP(15);
 }
 
 // ---- single-vector triangular solve: 64-wide diagonal block by one wave (lane = equation) ---------------------
@@ -455,8 +491,8 @@ inline int split(int n, int base = NB) {
 
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
     if (n <= 0 || nrhs <= 0) return 0;
-    if (!trans && g_strip && n <= SB) {
-        trsm_strip_kernel<<<gpk_ceil_div(nrhs, SNC), 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs);
+    if (!trans && g_strip && n <= SB && (n & 15) == 0) {
+        trsm_strip_kernel<<<gpk_ceil_div(nrhs, SNC), SNT, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -467,7 +503,7 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    const int n1 = split(n, (!trans && g_strip) ? SB : NB), n2 = n - n1;
+    const int n1 = split(n, (!trans && g_strip && n > SB) ? SB : NB), n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     const double* L22 = L21 + n1;
     double* B2 = B + (long)n1 * ldb;
@@ -493,8 +529,8 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
     int clo = lead - (row0 + n);
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
-    if (g_strip && n <= SB) {
-        trsm_strip_kernel<<<gpk_ceil_div(nrhs - clo, SNC), 256, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo);
+    if (g_strip && n <= SB && (n & 15) == 0) {
+        trsm_strip_kernel<<<gpk_ceil_div(nrhs - clo, SNC), SNT, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, g_dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -503,7 +539,7 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    const int n1 = split(n, g_strip ? SB : NB), n2 = n - n1;
+    const int n1 = split(n, (g_strip && n > SB) ? SB : NB), n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     double* B2 = B + (long)n1 * ldb;
     GPK_TRY(gpk_i_trsm_left_lz(h, L, n1, ldl, B, nrhs, ldb, lead, row0));

@@ -65,6 +65,7 @@ PROTOTYPES = {
     'gpk_debug_stamps': (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     'gpk_ubench_mfma_f64': (_i, [_vp, _i, _pd]),
     'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
+    'gpk_ubench_latency': (_i, [_vp, _i, _pd]),
 }
 
 _lib = None

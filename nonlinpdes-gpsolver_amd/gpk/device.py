@@ -289,6 +289,11 @@ class Context:
         self._chk(self.lib.gpk_ubench_mfma_f64(self.h, iters, C.byref(v)))
         return v.value
 
+    def ubench_latency(self, mode):
+        v = C.c_double()
+        self._chk(self.lib.gpk_ubench_latency(self.h, int(mode), C.byref(v)))
+        return v.value
+
     def ubench_hbm_write(self, nbytes=1 << 30, iters=10):
         v = C.c_double()
         self._chk(self.lib.gpk_ubench_hbm_write(self.h, nbytes, iters, C.byref(v)))
