@@ -10,6 +10,8 @@
 #define GPK_ERR_ARG (-9001)
 #define GPK_ERR_NODEV (-9002)
 
+constexpr int GPK_MAX_TRSV_BLOCKS = 4096;
+
 struct gpk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -17,6 +19,8 @@ struct gpk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int* d_info = nullptr;          // device int: first non-positive pivot (1-based), 0 = none
     double* d_scalars = nullptr;    // small device scratch for reductions (16 doubles)
+    int* d_flags = nullptr;         // per-block "solved" epochs of the fused single-vector triangular solve (GPK_MAX_TRSV_BLOCKS ints)
+    int trsv_epoch = 0;
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
