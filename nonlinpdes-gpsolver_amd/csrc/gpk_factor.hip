@@ -54,24 +54,24 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane /* wave-unif
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base, int dbg) {
-    GPK_STAMP(0);
-    __shared__ double As[NB * XS];                                  // As[r*XS + c]
-    __shared__ __attribute__((aligned(16))) double Ps[NB * RB];     // factored panel, Ps[r*16 + i] = L[r][r0+i]
+// stage a <=64 x <=64 diagonal block into LDS (identity-padded): one round trip, each wave fetches 16 rows
+__device__ __forceinline__ void potf2_stage(const double* __restrict__ A, long lda, int n, double* __restrict__ As) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cl = min(lane, n - 1);
-    {                                                               // one round trip: each wave fetches 16 rows
-        double t[RB];
+    double t[RB];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) t[u] = A[(long)min(wave * RB + u, n - 1) * lda + cl];
+    for (int u = 0; u < RB; ++u) t[u] = A[(long)min(wave * RB + u, n - 1) * lda + cl];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int r = wave * RB + u;
-            As[r * XS + lane] = (r < n && lane < n) ? t[u] : ((r == lane) ? 1.0 : 0.0);   // identity padding
-        }
+    for (int u = 0; u < RB; ++u) {
+        const int r = wave * RB + u;
+        As[r * XS + lane] = (r < n && lane < n) ? t[u] : ((r == lane) ? 1.0 : 0.0);   // identity padding
     }
-    __syncthreads();
-    GPK_STAMP(1);
+}
+
+// in-place Cholesky of the staged block (As[r*XS + c], lower triangle valid on return); returns the 1-based index of the
+// first non-positive pivot (0 = none), wave-uniform.  Called by all 256 threads; ends with a barrier.
+__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Ps, int n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int bad = 0;
     const int nblk = (n + RB - 1) / RB;
     for (int kb = 0; kb < nblk; ++kb) {
@@ -114,12 +114,28 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long
         }
         __syncthreads();
     }
-    GPK_STAMP(2);
+    return bad;
+}
+
+__device__ __forceinline__ void potf2_store(double* __restrict__ A, long lda, int n, const double* __restrict__ As) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
         const int r = wave * RB + u;
         if (r < n && lane <= r) A[(long)r * lda + lane] = As[r * XS + lane];
     }
+}
+
+__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base, int dbg) {
+    GPK_STAMP(0);
+    __shared__ double As[NB * XS];                                  // As[r*XS + c]
+    __shared__ __attribute__((aligned(16))) double Ps[NB * RB];     // factored panel, Ps[r*16 + i] = L[r][r0+i]
+    potf2_stage(A, lda, n, As);
+    __syncthreads();
+    GPK_STAMP(1);
+    const int bad = potf2_tile(As, Ps, n);
+    GPK_STAMP(2);
+    potf2_store(A, lda, n, As);
     if (bad && bad <= n && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     GPK_STAMP(3);
 }
@@ -134,16 +150,20 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long
 // remaining equations are updated a quarter per wave (16 FMAs per broadcast ds_read_b128 pair), one barrier per block.
 // A single wave doing all of it was LDS-issue bound at ~25 us per launch; ~130 + 63 such launches sit on the critical
 // path of every Gauss-Newton step.
+struct TrsmShared {
+    __attribute__((aligned(16))) double Ws[NB * WS];                 // Ws[a*WS + b]: coefficient of x_b in equation a
+    double Xs[NB * XS];                                              // right-hand sides, Xs[a*XS + lane]
+    double Ys[NB * XS];                                              // solved values
+    double rds[NB];                                                  // 1 / diagonal
+};
+
+// L may point to global memory or (fused panel kernel) to the factored diagonal block staged in LDS (ldl = XS then).
 template <bool TRANS, bool ROWVEC>
-__global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict__ L, long ldl, int nb,
-                                                        double* __restrict__ B, long ldb, int ncols, int dbg) {
-    GPK_STAMP(4);
-    __shared__ __attribute__((aligned(16))) double Ws[NB * WS];      // Ws[a*WS + b]: coefficient of x_b in equation a
-    __shared__ double Xs[NB * XS];                                   // right-hand sides, Xs[a*XS + lane]
-    __shared__ double Ys[NB * XS];                                   // solved values
-    __shared__ double rds[NB];                                       // 1 / diagonal
+__device__ __forceinline__ void trsm_base_body(TrsmShared& sh, const double* __restrict__ L, long ldl, int nb,
+                                               double* __restrict__ B, long ldb, int ncols, int blk, int dbg) {
+    double* const Ws = sh.Ws; double* const Xs = sh.Xs; double* const Ys = sh.Ys; double* const rds = sh.rds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * NB;
+    const int c0 = blk * NB;
     const int c = c0 + lane;
     const int lc = min(lane, nb - 1);
     const int nr = ROWVEC ? min(NB, ncols - c0) : nb;                // rows of the B tile as stored in memory
@@ -228,6 +248,34 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
         }
     }
     GPK_STAMP(9);
+}
+
+template <bool TRANS, bool ROWVEC>
+__global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict__ L, long ldl, int nb,
+                                                        double* __restrict__ B, long ldb, int ncols, int dbg) {
+    GPK_STAMP(4);
+    __shared__ TrsmShared sh;
+    trsm_base_body<TRANS, ROWVEC>(sh, L, ldl, nb, B, ldb, ncols, blockIdx.x, dbg);
+}
+
+// ---- Cholesky panel step, fused: factor the <=64-wide diagonal block AND solve the rows below against it ----------
+// Workgroup 0 factors A_jj and writes it back; every other workgroup owns 64 rows below, factors its own copy of A_jj
+// in LDS (redundant, but off nobody's critical path: the alternative is a second launch that first waits for the
+// factor to travel through memory) and solves X L_jj^T = A_rj by substitution.  One launch instead of two per panel.
+__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, long lda, int nb, int below,
+                                                          int* info, int pivot_base, int dbg) {
+    __shared__ double As[NB * XS];
+    __shared__ __attribute__((aligned(16))) double Ps[NB * RB];
+    __shared__ TrsmShared sh;
+    potf2_stage(A, lda, nb, As);
+    __syncthreads();
+    const int bad = potf2_tile(As, Ps, nb);
+    if (blockIdx.x == 0) {
+        potf2_store(A, lda, nb, As);
+        if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
+    } else {
+        trsm_base_body<false, true>(sh, As, XS, nb, A + (long)nb * lda, lda, below, (int)blockIdx.x - 1, 0);
+    }
 }
 
 // ---- forward substitution with a <=256-wide diagonal block, fused: one launch per 256-row strip ------------------------
@@ -572,6 +620,7 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
 
 int g_dbg = 0;
 int g_mt_trsm = 0;
+int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
 inline int split(int n, int base = NB) {
@@ -726,11 +775,16 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
         for (int j0 = k0; j0 < k0 + ob; j0 += NB) {
             const int nb = (k0 + ob - j0 < NB) ? k0 + ob - j0 : NB;
             double* Ajj = A + (long)j0 * lda + j0;
-            potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
             const int below = n - (j0 + nb);
+            if (g_fused_panel) {
+                potrf_panel_kernel<<<1 + gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0, g_dbg);
+            } else {
+                potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
+                if (below > 0)
+                    trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, g_dbg);
+            }
             if (below > 0) {
                 double* Abj = A + (long)(j0 + nb) * lda + j0;
-                trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, Abj, lda, below, g_dbg);
                 const int pc = k0 + ob - (j0 + nb);                   // remaining columns of this outer panel
                 if (pc > 0) {
                     // A[j0+nb:, j0+nb : k0+ob] -= L[j0+nb:, j] * L[j0+nb : k0+ob, j]^T   (rows above the diagonal
@@ -796,6 +850,7 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 extern "C" int gpk_debug_set_mt_trsm(int v) { g_mt_trsm = v; return 0; }
 extern "C" int gpk_debug_set_strip(int v) { g_strip = v; return 0; }
 extern "C" int gpk_debug_set_fused_trsv(int v) { g_fused_trsv = v; return 0; }
+extern "C" int gpk_debug_set_fused_panel(int v) { g_fused_panel = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

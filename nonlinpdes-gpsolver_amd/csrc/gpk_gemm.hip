@@ -401,12 +401,14 @@ static int g_force_cfg = 0;          // development aid (gpk_debug_set key 0): 0
 extern "C" int gpk_debug_set_mt_trsm(int v);
 extern "C" int gpk_debug_set_strip(int v);
 extern "C" int gpk_debug_set_fused_trsv(int v);
+extern "C" int gpk_debug_set_fused_panel(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
     if (key == 2) return gpk_debug_set_mt_trsm(value);
     if (key == 3) return gpk_debug_set_strip(value);
     if (key == 4) return gpk_debug_set_fused_trsv(value);
+    if (key == 5) return gpk_debug_set_fused_panel(value);
     return GPK_ERR_ARG;
 }
 
