@@ -158,9 +158,24 @@ struct TrsmShared {
 };
 
 // L may point to global memory or (fused panel kernel) to the factored diagonal block staged in LDS (ldl = XS then).
+// pre != nullptr: the right-hand sides were fetched by the caller (trsm_base_fetch) before L was ready.
+template <bool ROWVEC>
+__device__ __forceinline__ void trsm_base_fetch(const double* __restrict__ B, long ldb, int nb, int ncols, int blk, double (&tx)[RB]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = blk * NB;
+    const int lc = min(lane, nb - 1), cc = min(c0 + lane, ncols - 1);
+    const int nr = ROWVEC ? min(NB, ncols - c0) : nb;
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+        const int r = wave * RB + u;
+        tx[u] = ROWVEC ? B[(long)(c0 + min(r, nr - 1)) * ldb + lc] : B[(long)min(r, nb - 1) * ldb + cc];
+    }
+}
+
 template <bool TRANS, bool ROWVEC>
 __device__ __forceinline__ void trsm_base_body(TrsmShared& sh, const double* __restrict__ L, long ldl, int nb,
-                                               double* __restrict__ B, long ldb, int ncols, int blk, int dbg) {
+                                               double* __restrict__ B, long ldb, int ncols, int blk, int dbg,
+                                               const double (*pre)[RB] = nullptr) {
     double* const Ws = sh.Ws; double* const Xs = sh.Xs; double* const Ys = sh.Ys; double* const rds = sh.rds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c0 = blk * NB;
@@ -177,7 +192,7 @@ __device__ __forceinline__ void trsm_base_body(TrsmShared& sh, const double* __r
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const int r = wave * RB + u;
-            tx[u] = ROWVEC ? B[(long)(c0 + min(r, nr - 1)) * ldb + lc] : B[(long)min(r, nb - 1) * ldb + cc];
+            tx[u] = pre ? (*pre)[u] : (ROWVEC ? B[(long)(c0 + min(r, nr - 1)) * ldb + lc] : B[(long)min(r, nb - 1) * ldb + cc]);
         }
         GPK_STAMP(5);
 #pragma unroll
@@ -267,6 +282,8 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     __shared__ double As[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ps[NB * RB];
     __shared__ TrsmShared sh;
+    double tx[RB];                                                   // this workgroup's rows: fetched before the factorisation
+    if (blockIdx.x > 0) trsm_base_fetch<true>(A + (long)nb * lda, lda, nb, below, (int)blockIdx.x - 1, tx);
     potf2_stage(A, lda, nb, As);
     __syncthreads();
     const int bad = potf2_tile(As, Ps, nb);
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
         potf2_store(A, lda, nb, As);
         if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     } else {
-        trsm_base_body<false, true>(sh, As, XS, nb, A + (long)nb * lda, lda, below, (int)blockIdx.x - 1, 0);
+        trsm_base_body<false, true>(sh, As, XS, nb, A + (long)nb * lda, lda, below, (int)blockIdx.x - 1, 0, &tx);
     }
 }
 
