@@ -70,51 +70,63 @@ __device__ __forceinline__ void potf2_stage(const double* __restrict__ A, long l
 
 // in-place Cholesky of the staged block (As[r*XS + c], lower triangle valid on return); returns the 1-based index of the
 // first non-positive pivot (0 = none), wave-uniform.  Called by all 256 threads; ends with a barrier.
-__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Ps, int n) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int bad = 0;
-    const int nblk = (n + RB - 1) / RB;
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int r0 = kb * RB;
-        // Every wave holds all 64 rows (lane = row) and factors the 16-column panel redundantly: the four waves sit on
-        // four different SIMDs, so this costs no time and saves a hand-off; the trailing update is then split 4 ways.
-        double a[RB];
+// Unblocked right-looking, one barrier per column: thread = (row r, wave w) keeps 16 entries of row r in registers, the
+// columns {8i + 2w, 8i + 2w + 1}, i = 0..7 (cyclic in pairs, so all four waves stay busy to the last column and a pair is
+// one 16-byte broadcast read).  Column j: the wave that owns it takes the pivot from lane j, scales its column
+// (v_rsq_f64 + Newton, as LAPACK's dpotf2 scales by the reciprocal) and publishes it through a double-buffered LDS
+// vector; after the barrier every thread subtracts l[r] * l[c] from the columns c > j it owns.  The chain per column
+// is pivot broadcast -> rsqrt -> LDS round trip -> one FMA; the previous version (16-column panels factored redundantly
+// by every wave with 2 x (15 - j) lane broadcasts per column, then a blocked update) spent ~680 cycles per column.
+__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 2 x NB doubles, 16-byte aligned */, int n) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int r = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double a[16];
 #pragma unroll
-        for (int i = 0; i < RB; ++i) a[i] = As[lane * XS + r0 + i];
+    for (int i = 0; i < 8; ++i) {
+        a[2 * i] = As[r * XS + 8 * i + 2 * w];
+        a[2 * i + 1] = As[r * XS + 8 * i + 2 * w + 1];
+    }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const double d = bcast_lane(a[j], r0 + j);               // pivot lives in lane r0+j
-            if (!(d > 0.0) && bad == 0) bad = r0 + j + 1;            // NaN-safe, wave-uniform
+    for (int j = 0; j < NB; ++j) {
+        if (j >= n) continue;                                        // (uniform; `break` would keep the loop rolled)
+        const int wo = (j >> 1) & 3, jr = 2 * (j >> 3) + (j & 1);
+        double* __restrict__ lc = Lc + (j & 1) * NB;
+        if (w == wo) {
+            const double d = bcast_lane(a[jr], j);                   // pivot lives in lane j
             const double rs = rsqrt(d);                              // 1/sqrt(d), then one Newton step for sqrt(d)
             const double s0 = d * rs;
             const double sq = fma(fma(-s0, s0, d), 0.5 * rs, s0);
-            const double lij = a[j] * rs;                            // LAPACK dpotf2 also scales by the reciprocal
-            a[j] = (lane == r0 + j) ? sq : lij;                      // sqrt(d) only lands on the diagonal: off the
-#pragma unroll                                                       // dependency chain of the updates below
-            for (int k = j + 1; k < RB; ++k) a[k] -= lij * bcast_lane(lij, r0 + k);
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            Ps[lane * RB + i] = a[i];                                // identical values from every wave (benign)
-            if (wave == 0) As[lane * XS + r0 + i] = a[i];
-        }
-        for (int c = r0 + RB + 4 * wave; c < NB; c += 16) {          // trailing update of row `lane`: 4 columns per
-            const double* __restrict__ pc = Ps + c * RB;             // trip, column groups dealt round-robin to waves
-            double acc0 = As[lane * XS + c], acc1 = As[lane * XS + c + 1];
-            double acc2 = As[lane * XS + c + 2], acc3 = As[lane * XS + c + 3];
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                acc0 = fma(-a[i], pc[i], acc0);
-                acc1 = fma(-a[i], pc[RB + i], acc1);
-                acc2 = fma(-a[i], pc[2 * RB + i], acc2);
-                acc3 = fma(-a[i], pc[3 * RB + i], acc3);
-            }
-            As[lane * XS + c] = acc0; As[lane * XS + c + 1] = acc1;
-            As[lane * XS + c + 2] = acc2; As[lane * XS + c + 3] = acc3;
+            const double v = (r == j) ? sq : a[jr] * rs;
+            a[jr] = v;
+            lc[r] = v;
         }
         __syncthreads();
+        const double ml = lc[r];
+#pragma unroll
+        for (int i = j >> 3; i < 8; ++i) {
+            const d2 m = *reinterpret_cast<const d2*>(lc + 8 * i + 2 * w);
+            if (i == (j >> 3)) {                                     // the pair group that contains column j: mask c <= j
+                const int c0 = 8 * i + 2 * w;
+                a[2 * i] = (c0 > j) ? fma(-ml, m.x, a[2 * i]) : a[2 * i];       // select the RESULT: a NaN column must not
+                a[2 * i + 1] = (c0 + 1 > j) ? fma(-ml, m.y, a[2 * i + 1]) : a[2 * i + 1];   // reach finished columns (info)
+            } else {
+                a[2 * i] = fma(-ml, m.x, a[2 * i]);
+                a[2 * i + 1] = fma(-ml, m.y, a[2 * i + 1]);
+            }
+        }
     }
-    return bad;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        As[r * XS + 8 * i + 2 * w] = a[2 * i];
+        As[r * XS + 8 * i + 2 * w + 1] = a[2 * i + 1];
+    }
+    __syncthreads();
+    // A non-positive (or NaN) pivot d gives rsqrt(d) = NaN or inf and a NaN on the diagonal, which then spreads: the
+    // first diagonal entry that is not > 0 marks the first bad pivot (LAPACK's info), every earlier one is finite.
+    const bool flag = (r < n) && !(As[r * XS + r] > 0.0);
+    const unsigned long long mask = __ballot(flag);
+    return mask ? (int)__builtin_ctzll(mask) + 1 : 0;
 }
 
 __device__ __forceinline__ void potf2_store(double* __restrict__ A, long lda, int n, const double* __restrict__ As) {
