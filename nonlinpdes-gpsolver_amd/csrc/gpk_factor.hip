@@ -94,10 +94,15 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
         double* __restrict__ lc = Lc + (j & 1) * NB;
         if (w == wo) {
             const double d = bcast_lane(a[jr], j);                   // pivot lives in lane j
-            const double rs = rsqrt(d);                              // 1/sqrt(d), then one Newton step for sqrt(d)
-            const double s0 = d * rs;
-            const double sq = fma(fma(-s0, s0, d), 0.5 * rs, s0);
-            const double v = (r == j) ? sq : a[jr] * rs;
+            // 1/sqrt(d) and sqrt(d) by coupled Newton iterations from v_rsq_f64: g -> sqrt(d), hh -> 1/(2 sqrt(d))
+            const double y0 = __builtin_amdgcn_rsq(d);
+            double g = d * y0, hh = 0.5 * y0;
+            double e = fma(-g, hh, 0.5);
+            g = fma(g, e, g); hh = fma(hh, e, hh);
+            e = fma(-g, hh, 0.5);
+            g = fma(g, e, g); hh = fma(hh, e, hh);
+            const double sq = fma(fma(-g, g, d), hh, g);             // one more correction for the diagonal entry
+            const double v = (r == j) ? sq : a[jr] * (hh + hh);      // LAPACK dpotf2 also scales by the reciprocal
             a[jr] = v;
             lc[r] = v;
         }
