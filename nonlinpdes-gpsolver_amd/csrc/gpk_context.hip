@@ -32,8 +32,8 @@ extern "C" int gpk_create(int device, gpk_handle* out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_info, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, 64 * sizeof(double));
     if (e == hipSuccess) e = hipMemset(h->d_info, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_flags, GPK_MAX_TRSV_BLOCKS * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(h->d_flags, 0, GPK_MAX_TRSV_BLOCKS * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_flags, (GPK_MAX_TRSV_BLOCKS + 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->d_flags, 0, (GPK_MAX_TRSV_BLOCKS + 1) * sizeof(int));
     if (e != hipSuccess) { delete h; return -(int)e; }
     h->stream = h->own_stream;
     hipDeviceProp_t prop;

@@ -294,17 +294,30 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
 // Workgroup 0 factors A_jj and writes it back; every other workgroup owns 64 rows below, factors its own copy of A_jj
 // in LDS (redundant, but off nobody's critical path: the alternative is a second launch that first waits for the
 // factor to travel through memory) and solves X L_jj^T = A_rj by substitution.  One launch instead of two per panel.
+// A_jj is overwritten in place, so workgroup 0 may only store once every other workgroup has READ the unfactored block
+// -- including those the hardware dispatches late when the grid exceeds what is resident (n > ~16000).  Each workgroup
+// takes a ticket on a global counter after its loads have landed; workgroup 0 waits for the running total `target`
+// (the counter is never reset: the host passes the cumulative number of tickets).  Nobody ever waits for workgroup 0.
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, long lda, int nb, int below,
-                                                          int* info, int pivot_base, int dbg) {
+                                                          int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
     __shared__ double As[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ps[NB * RB];
     __shared__ TrsmShared sh;
     double tx[RB];                                                   // this workgroup's rows: fetched before the factorisation
     if (blockIdx.x > 0) trsm_base_fetch<true>(A + (long)nb * lda, lda, nb, below, (int)blockIdx.x - 1, tx);
     potf2_stage(A, lda, nb, As);
-    __syncthreads();
+    __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
+    if (blockIdx.x > 0 && threadIdx.x == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int bad = potf2_tile(As, Ps, nb);
     if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {
+            int it = 0;                                              // (int) difference: robust to wrap-around of the counter
+            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++it > (1 << 24)) break;                         // cannot happen: the other workgroups never wait
+            }
+        }
+        __syncthreads();
         potf2_store(A, lda, nb, As);
         if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     } else {
@@ -811,7 +824,10 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
             double* Ajj = A + (long)j0 * lda + j0;
             const int below = n - (j0 + nb);
             if (g_fused_panel) {
-                potrf_panel_kernel<<<1 + gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0, g_dbg);
+                const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
+                h->panel_loaded += (unsigned)nrb;
+                potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                    (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), h->panel_loaded, g_dbg);
             } else {
                 potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
                 if (below > 0)

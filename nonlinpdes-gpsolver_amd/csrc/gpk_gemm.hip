@@ -427,12 +427,11 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     if (k <= 64 && !lower_only && g_force_cfg == 0 &&
         (beta == 0.0 || (beta == 1.0 && (alpha == 1.0 || alpha == -1.0))))
         return launch_k64(h, ta, tb, g);
-    // big tiles once they fill the chip (256 CUs x 2 resident workgroups); small tiles keep more CUs busy otherwise
-    const long tm = gpk_ceil_div(m, 128), tn = gpk_ceil_div(n, 128);
-    const long big_tiles = lower_only ? tm * (tm + 1) / 2 : tm * tn;
-    // measured (tools/gemm_sweep.py): the 64x64 configuration matches or beats 128x128 up to ~1500 big tiles (less
-    // tail quantisation over 256 CUs); the big tiles win once there are >= 6 of them per CU
-    const bool big = g_force_cfg ? (g_force_cfg == 1) : (big_tiles >= ((ta && !tb && !lower_only) ? 900 : 1536));
+    // The 64x64 configuration (4 workgroups per CU, two slabs in flight) is used for every shape: with the straight-line
+    // two-slab prefetch it beats the 128x128 one (2 per CU, 232 VGPRs, one slab in flight) from 2048 to 21000 on every
+    // operand layout (tools/gemm_big_probe.py: 62.0 vs 58.8 TF/s NN 10500^3-ish, 58.6 vs 49.8 NT K=512).  The large
+    // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
+    const bool big = (g_force_cfg == 1);
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
     return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
 }

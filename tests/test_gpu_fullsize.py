@@ -113,3 +113,33 @@ def test_gauss_newton_reaches_truth_full_size(setup):
     sol = z.download()
     err = O.elliptic_truth(Xd[:, 0], Xd[:, 1]) - sol
     assert np.sqrt(np.sum(err ** 2) / ND) < 1e-6
+
+
+def test_cholesky_more_row_blocks_than_resident_workgroups():
+    """N = 17000: the first panels of the factorisation launch > 256 workgroups (one per 64 rows below the diagonal
+    block), more than are resident at once, so some start after the owner of the diagonal block has finished factoring
+    it.  The in-place write-back of the diagonal block must wait for them (regression: info = 16385 at N = 21000)."""
+    import gpk
+    ctx = gpk.Context(0)
+    np.random.seed(3)
+    from src.sample_points import sampled_pts_rdm
+    Xd, Xb = sampled_pts_rdm(8300, 400, np.array([[0, 1], [0, 1]]))
+    N = 2 * 8300 + 400
+    T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', SIGMA, Xd, Xb, 1e-8, 'adaptive')
+    L = T.clone()
+    assert ctx.potrf(L) == 0
+    ctx.tril(L)
+    ctx.gemm(0, 1, N, N, N, -1.0, L, L, 1.0, T)                 # T <- Theta - L L^T on the device
+    d = T.download()
+    p = 1.0 / SIGMA ** 2
+    assert np.max(np.abs(d)) <= 1e-11 * 8 * p * p                # entries of Theta are O(8/sigma^4) = 5000
+    # a triangular solve with one vector through the fused kernel at this size (266 chained workgroups)
+    rng = np.random.RandomState(4)
+    b = rng.normal(size=N)
+    x = ctx.array(b)
+    ctx.trsm(L, x)
+    Lh = L.download()
+    xh = x.download().ravel()
+    assert np.all(np.isfinite(xh))
+    assert np.linalg.norm(Lh @ xh - b) <= 1e-12 * np.linalg.norm(Lh) * np.linalg.norm(xh)   # backward-stable substitution
+    ctx.close()
