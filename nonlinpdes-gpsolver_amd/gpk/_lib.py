@@ -95,5 +95,9 @@ def load_library():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    # development aid: GPK_DEBUG_SET="6=0,0=1" applies gpk_debug_set(key, value) pairs at load time (A/B runs of bench.py)
+    for kv in filter(None, os.environ.get('GPK_DEBUG_SET', '').split(',')):
+        k, v = kv.split('=')
+        lib.gpk_debug_set(int(k), int(v))
     _lib = lib
     return lib

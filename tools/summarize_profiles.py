@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof (tools/profile_round.sh) -> profiles/<round>_*: kernel stats table, bench lines, PMC summary of the
+dominant kernel (SYRK = gemm_f64_kernel<...,true,false> with the largest grid) and of the assembly kernel.
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB units; on gfx950
+FETCH_SIZE tallies the 128-byte requests of 16-byte-per-lane streaming reads as 64 bytes -> x2 for kernels that read
+with dwordx4 (the GEMM); WRITE_SIZE needs no correction (calibrated on the assembly kernel, which writes exactly 8 N^2
+bytes)."""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, 'gpurun_out', 'prof')
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+DST = os.path.join(ROOT, 'profiles')
+
+def one(pattern):
+    g = glob.glob(os.path.join(SRC, pattern), recursive=True)
+    return g[0] if g else None
+
+def counters(name):
+    f = one(f'pmc_{name}/**/*counter_collection.csv')
+    out = {}
+    if not f:
+        return out
+    for r in csv.DictReader(open(f)):
+        k = (int(r['Dispatch_Id']), r['Kernel_Name'], int(r['Grid_Size']))
+        d = out.setdefault(k, {'dur_us': (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3})
+        d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+    return out
+
+def pick(table, pred):
+    rows = [v for k, v in table.items() if pred(k)]
+    return rows
+
+def mean(rows, key):
+    vals = [r[key] for r in rows if key in r]
+    return sum(vals) / len(vals) if vals else None
+
+stats = one('stats/**/*kernel_stats.csv')
+if stats:
+    shutil.copy(stats, os.path.join(DST, f'{tag}_bench_kernel_stats.csv'))
+for src, dst in [('bench.json', f'{tag}_bench.json'), ('bench_under_rocprof.json', f'{tag}_bench_under_rocprof.json')]:
+    p = os.path.join(SRC, src)
+    if os.path.exists(p):
+        lines = [l for l in open(p).read().splitlines() if l.startswith('{')]
+        if lines:
+            open(os.path.join(DST, dst), 'w').write(json.dumps(json.loads(lines[-1]), indent=1) + '\n')
+
+is_syrk = lambda k: 'gemm_f64_kernel' in k[1] and 'true, false' in k[1]
+is_asm = lambda k: 'assemble_kernel' in k[1]
+summary = {'kernel': 'gemm_f64_kernel<64,64,32,32,TN> (SYRK Hb = S^T S, lower tiles), BASELINE config 2'}
+fetch, write = counters('FETCH_SIZE'), counters('WRITE_SIZE')
+busy, tcc = counters('SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE'), counters('TCC_HIT_sum+TCC_MISS_sum')
+fs, ws = pick(fetch, is_syrk), pick(write, is_syrk)
+if fs and ws:
+    f_kib, w_kib = mean(fs, 'FETCH_SIZE'), mean(ws, 'WRITE_SIZE')
+    summary.update({'launches_sampled': len(fs), 'FETCH_SIZE_KiB_raw': f_kib, 'WRITE_SIZE_KiB_raw': w_kib,
+                    'correction': 'FETCH_SIZE x2 (16-byte-per-lane reads, gfx950), WRITE_SIZE x1; KiB units',
+                    'fetch_bytes_corrected': f_kib * 1024 * 2, 'write_bytes': w_kib * 1024,
+                    'hbm_bytes_per_launch': f_kib * 1024 * 2 + w_kib * 1024,
+                    'avg_duration_us_under_pmc': mean(fs, 'dur_us')})
+bs = pick(busy, is_syrk)
+if bs:
+    b, g = mean(bs, 'SQ_VALU_MFMA_BUSY_CYCLES'), mean(bs, 'GRBM_GUI_ACTIVE')
+    summary.update({'SQ_VALU_MFMA_BUSY_CYCLES': b, 'GRBM_GUI_ACTIVE': g,
+                    'mfma_busy_fraction': b / 1024 / (g / 8),
+                    'executed_flops_from_counter': b / 64 * 2048,
+                    'effective_clock_ghz': (g / 8) / (mean(bs, 'dur_us') * 1e3),
+                    'note': 'SQ_VALU_MFMA_BUSY_CYCLES = 64 cycles per v_mfma_f64_16x16x4_f64 summed over the 1024 SIMDs; '
+                            'GRBM_GUI_ACTIVE is summed over the 8 XCDs; mfma_busy_fraction = busy / 1024 / (GUI_ACTIVE / 8)'})
+ts = pick(tcc, is_syrk)
+if ts:
+    h, m = mean(ts, 'TCC_HIT_sum'), mean(ts, 'TCC_MISS_sum')
+    summary.update({'TCC_HIT_sum': h, 'TCC_MISS_sum': m, 'l2_hit_rate': h / (h + m)})
+fa, wa = pick(fetch, is_asm), pick(write, is_asm)
+if fa and wa:
+    summary['assemble_kernel'] = {'WRITE_SIZE_KiB': mean(wa, 'WRITE_SIZE'), 'FETCH_SIZE_KiB_raw': mean(fa, 'FETCH_SIZE'),
+                                  'write_bytes': mean(wa, 'WRITE_SIZE') * 1024, 'avg_duration_us_under_pmc': mean(wa, 'dur_us')}
+bench = os.path.join(DST, f'{tag}_bench.json')
+if os.path.exists(bench):
+    rl = json.load(open(bench)).get('roofline', {})
+    summary['algorithmic_flops_per_launch'] = rl.get('flops_per_launch')
+open(os.path.join(DST, f'{tag}_pmc_syrk.json'), 'w').write(json.dumps(summary, indent=1) + '\n')
+print(json.dumps(summary, indent=1))
