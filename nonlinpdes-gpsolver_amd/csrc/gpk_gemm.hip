@@ -137,10 +137,21 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& tm, int& tn) {
     // (no per-XCD chunking then: contiguous chunks of a work ramp would load the XCDs unevenly; round-robin keeps them level)
     if (g.lead > 0) logical = nwg - 1 - b;
     if (g.lower_only) {
+        if (g.lead > 0) logical = b;
         int i = (int)((sqrt(8.0 * (double)logical + 1.0) - 1.0) * 0.5);
         while ((long)(i + 1) * (i + 2) / 2 <= logical) ++i;
         while ((long)i * (i + 1) / 2 > logical) --i;
-        tm = i; tn = logical - i * (i + 1) / 2;
+        if (g.lead > 0) {
+            // leading zeros: work depends on the column block only.  Column-major from the right-most (longest) column:
+            // strictly longest-first, and the tiles of a column -- same K range, dispatched back to back, every 8th on
+            // the same XCD -- walk their shared column panel in step (L2 reuse without a static per-XCD partition).
+            tn = g.ntm - 1 - i; tm = tn + (logical - i * (i + 1) / 2);
+        } else {
+            tm = i; tn = logical - i * (i + 1) / 2;
+        }
+    } else if (g.lead > 0) {
+        tn = g.ntn - 1 - b / g.ntm;                                   // column-major from the longest column, as above
+        tm = b % g.ntm;
     } else {
         constexpr int GROUP = 8;
         const int per_group = GROUP * g.ntn;
