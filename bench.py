@@ -297,8 +297,8 @@ def run_sharded(args, workload):
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
-                       'parallelism': f'panel-sharded Cholesky (block-cyclic columns, width {args.panel}, RCCL broadcast) + '
-                                      f'column-sharded TRSM + all-gather(S) + row-block-sharded SYRK over {world} rank(s)',
+                       'parallelism': f'Theta: panel-sharded Cholesky (block-cyclic columns, width {args.panel}, RCCL broadcast); step: '
+                                      f'column-sharded TRSM + all-gather(S) + row-block-sharded SYRK + all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)',
                        'formulation': 'dense F1, nothing cached across steps'},
             'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': args.warmup + args.steps,
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},

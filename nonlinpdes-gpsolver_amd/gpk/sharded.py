@@ -12,8 +12,9 @@ Cholesky (Theta, and the bordered Gauss-Newton matrix Hb):  1-D block-cyclic BLO
         rank r:  update the block columns j > k with j mod P == r                (gpk_gemm, MFMA)
 Gauss-Newton step:  S = L^{-1}[A | F] is independent per right-hand-side column -> rank r solves its column range with
     the replicated L (no communication), the column shards are all-gathered (every rank needs all of S for its rows of
-    Hb = S^T S), block rows of Hb are computed cyclically and all-gathered, Hb is factored by the panel scheme above and
-    the two small triangular solves + update are replicated, so all ranks hold the same iterate bit for bit.
+    Hb = S^T S), block rows of Hb are computed cyclically and all-gathered, Hb is factored REPLICATED on every rank (cheaper
+    than the panel scheme at this size, see gn_step) and the small triangular solve + update are replicated, so all ranks
+    hold the same iterate bit for bit.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a panel broadcast moves <= 139 MB at C5, the S all-gather 4.35 GB
 in total, Hb 2 GB; nothing here is a ring all-reduce.
 """
@@ -206,9 +207,14 @@ class ShardedFactorSolve:
                     Hb[i0:i0 + ib, :nc].copy_(parts[r][t * nb:t * nb + ib, :nc])
             del parts, mine
         loss_in = float(Hb[nz, nz].item())
-        info = self.potrf(Hb, nc)                                  # bordered: last row of the factor = L_H^{-1} g / 2
+        # Every rank now holds all of Hb and factors it locally (replicated, no communication): at n_z = 16000 one GPU
+        # needs ~37 ms (27 ms of GEMM + the 250-panel latency chain), while the panel-broadcast scheme pays per 512-wide
+        # panel an owner-only factorisation (~0.9 ms) and a broadcast (~0.4 ms) on top of update/P -- 32 panels cost
+        # more than the replicated factorisation at every P >= 2.  (Theta itself is factored once with the sharded scheme.)
+        info = ops.potrf(Hb, 0, nc)                                # bordered: last row of the factor = L_H^{-1} g / 2
         if info == nc:
             info = 0                                               # the border pivot is not part of H
+        info = comm.max_int(info, Hb.device)
         delta.copy_(Hb[nz, :nz])
         ops.trsv(Hb, nz, delta, True)                              # replicated: L_H^{-T} y
         ops.axpy(nz, -float(step_size), delta, z)
