@@ -1,0 +1,73 @@
+"""Schedule variants must agree.  Every fused / reordered kernel added for speed keeps its plainer predecessor behind
+gpk_debug_set (development aid, include/gpk.h): the same Gauss-Newton steps are run under each variant at a size where
+all of them are active (256-row strips, several Cholesky panels, several chained TRSV blocks, > 1 supertile) and the
+iterates compared -- same operation, different schedule, so agreement is to rounding (amplified by the conditioning of
+Theta at the nugget used)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O
+
+VARIANTS = [
+    ('default', {}),
+    ('64-row base solves instead of 256-row strips', {3: 0}),
+    ('two launches per TRSV block', {4: 0}),
+    ('potf2 + trsm launches per Cholesky panel', {5: 0}),
+    ('supertile schedule of the leading-zero SYRK', {6: 1}),
+    ('128x128 GEMM tiles', {0: 1}),
+]
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0}
+
+
+def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
+    import gpk
+    for k, v in DEFAULTS.items():
+        ctx.lib.gpk_debug_set(k, v)
+    for k, v in variant.items():
+        ctx.lib.gpk_debug_set(k, v)
+    try:
+        T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, nugget, 'adaptive')
+        assert ctx.potrf(T) == 0
+        prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Xd.shape[0], Xb.shape[0], f, g, T, p0=1.0, p1=3.0)
+        z = ctx.array(init)
+        hist = []
+        for _ in range(steps):
+            loss, info = ctx.gn_step(prob, z, 1.0)
+            assert info == 0
+            hist.append(loss)
+        hist.append(ctx.gn_loss(prob, z))
+        return z.download().ravel().copy(), np.array(hist)
+    finally:
+        for k, v in DEFAULTS.items():
+            ctx.lib.gpk_debug_set(k, v)
+
+
+def test_schedule_variants_agree():
+    import gpk
+    ctx = gpk.Context(0)
+    np.random.seed(5)
+    from src.sample_points import sampled_pts_rdm
+    Nd, Nb = 1100, 160                                           # N = 2360 (10 strips), n_z = 1100 (18 panels / TRSV blocks)
+    Xd, Xb = sampled_pts_rdm(Nd, Nb, np.array([[0, 1], [0, 1]]))
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    init = np.random.normal(0.0, 1.0, Nd)
+    ref_z, ref_hist = _run(ctx, {}, Xd, Xb, f, g, init, 3, 1e-9)
+    truth = O.elliptic_truth(Xd[:, 0], Xd[:, 1])
+    assert np.sqrt(np.mean((ref_z - truth) ** 2)) < 1e-4
+    for name, variant in VARIANTS[1:]:
+        z, hist = _run(ctx, variant, Xd, Xb, f, g, init, 3, 1e-9)
+        assert np.max(np.abs(z - ref_z)) <= 1e-7 * np.max(np.abs(ref_z)), name
+        np.testing.assert_allclose(hist, ref_hist, rtol=1e-5, err_msg=name)
+    ctx.close()
+
+
+def test_latency_probes_run():
+    import gpk
+    ctx = gpk.Context(0)
+    vals = [ctx.ubench_latency(m) for m in range(7)]
+    print('\n[ubench] cycles/op: dep fma64 %.1f, indep fma64 %.1f, dep ds_read %.1f, indep ds_read %.1f, dep mfma %.1f, '
+          'dep global (1 line) %.1f, dep global (16 lines) %.1f' % tuple(vals))
+    assert all(0.5 < v < 5000 for v in vals)
+    ctx.close()
