@@ -486,6 +486,10 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
     const bool big = (g_force_cfg == 1);
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
+    // short-and-wide updates of the triangular-solve recursion (M = 256 or 512 against ~4000 columns): 64x64 tiles give
+    // only 1-2 workgroups per CU, i.e. one wave per SIMD and nothing to hide latency behind; 32x64 tiles double that
+    const long t64 = (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64);
+    if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
     return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
 }
 
