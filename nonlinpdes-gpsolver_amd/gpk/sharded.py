@@ -50,6 +50,13 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
+    def max_float(self, v, device):
+        if self.world == 1:
+            return float(v)
+        t = torch.tensor([float(v)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
     def barrier(self):
         if self.world > 1:
             dist.barrier(group=self.group)
