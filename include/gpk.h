@@ -97,6 +97,13 @@ int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs
 /* C <- alpha*op(A)*op(B) + beta*C; ta/tb = 1 means the operand is stored transposed (op(A) is m x k). */
 int gpk_gemm(gpk_handle h, int ta, int tb, int m, int n, int k, double alpha, const double* A, int lda,
              const double* B, int ldb, double beta, double* C, int ldc);
+/* Leading-zero variants used by the column-sharded Gauss-Newton step (gpk/sharded.py) on the [A(z) | F] block built by
+ * gpk_gn_build_rev: column c < lead of the right-hand side / of operand B is zero above row lead-1-c, columns >= lead are
+ * dense.  Same results as gpk_trsm / gpk_gemm(tb = 0); the zeros are skipped (contiguous active column ranges in the
+ * solve, late K start per tile in the product).  lead <= 0 degenerates to the dense routines. */
+int gpk_trsm_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead);
+int gpk_gemm_lz(gpk_handle h, int ta, int m, int n, int k, double alpha, const double* A, int lda,
+                const double* B, int ldb, double beta, double* C, int ldc, int lead);
 /* C <- alpha*A^T A + beta*C, A is k x n row-major; lower triangle only unless full != 0
  * (the 2*ss^T ss of src/PDEs.py:307 and of every autodiff Hessian_GN). */
 int gpk_syrk(gpk_handle h, int n, int k, double alpha, const double* A, int lda, double beta, double* C, int ldc, int full);
@@ -126,6 +133,9 @@ int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double
                 double* S, int lds, double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);
 /* building blocks of gpk_gn_step for the column-sharded multi-GPU step: S <- [A(z) | F(z)] (no solve), y += alpha x */
 int gpk_gn_build(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* S, int lds);
+/* Same with unknown j stored in column n_z-1-j (elliptic system only): column c < n_z of [A | F] is then zero above row
+ * n_z-1-c -- the layout gpk_gn_step uses internally and gpk_trsm_lz / gpk_gemm_lz exploit. */
+int gpk_gn_build_rev(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, int lds);
 int gpk_axpy(gpk_handle h, int n, double alpha, const double* x, double* y);
 /* loss(z) (src/PDEs.py:82-87,278-289,418-430,138-147; src/InverseProblems.py:105-120); work: s_rows doubles. */
 int gpk_gn_loss(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* work, double* host_loss);

@@ -926,6 +926,12 @@ extern "C" int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl
     return gpk_i_trsm_left_mt(h, trans != 0, L, n, ldl, B, nrhs, ldb);
 }
 
+extern "C" int gpk_trsm_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead) {
+    if (!h || !L || !B || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs) return GPK_ERR_ARG;
+    if (lead <= 0) return gpk_i_trsm_left_mt(h, false, L, n, ldl, B, nrhs, ldb);
+    return gpk_i_trsm_left_lz(h, L, n, ldl, B, nrhs, ldb, lead, 0);
+}
+
 extern "C" int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {
     if (!h || !L || !X || n < 0 || m < 0 || ldl < n || ldx < n) return GPK_ERR_ARG;
     return gpk_i_trsm_right_lt(h, L, n, ldl, X, m, ldx);

@@ -499,6 +499,12 @@ extern "C" int gpk_gemm(gpk_handle h, int ta, int tb, int m, int n, int k, doubl
     return gpk_i_gemm(h, ta != 0, tb != 0, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, false);
 }
 
+extern "C" int gpk_gemm_lz(gpk_handle h, int ta, int m, int n, int k, double alpha, const double* A, int lda,
+                           const double* B, int ldb, double beta, double* C, int ldc, int lead) {
+    if (!h) return GPK_ERR_ARG;
+    return gpk_i_gemm(h, ta != 0, false, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, false, lead > 0 ? lead : 0);
+}
+
 extern "C" int gpk_symmetrize_lower(gpk_handle h, double* A, int n, int lda) {
     if (!h || !A) return GPK_ERR_ARG;
     if (n <= 0) return 0;

@@ -282,6 +282,17 @@ extern "C" int gpk_gn_build(gpk_handle h, const gpk_gn_problem* p, const double*
     return build(h, &q, z, S, lds, d.nz, 1);
 }
 
+extern "C" int gpk_gn_build_rev(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, int lds) {
+    if (!h || !z || !S || !p) return GPK_ERR_ARG;
+    if (p->system != GPK_GN_ELLIPTIC) return gpk_bad_arg(h, "gn_build_rev: elliptic system only");
+    Dims d;
+    gpk_gn_problem q = *p;
+    if (gn_dims(&q, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
+    if (lds < d.nz + 1) return gpk_bad_arg(h, "gn: lds < nz+1");
+    GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
+    return build(h, &q, z, S, lds, d.nz, 1, 1);
+}
+
 extern "C" int gpk_axpy(gpk_handle h, int n, double alpha, const double* x, double* y) {
     if (!h || !x || !y || n < 0) return GPK_ERR_ARG;
     if (n == 0) return 0;

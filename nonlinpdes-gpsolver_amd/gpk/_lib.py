@@ -50,6 +50,8 @@ PROTOTYPES = {
     'gpk_tril': (_i, [_vp, _vp, _i, _i]),
     'gpk_symmetrize_lower': (_i, [_vp, _vp, _i, _i]),
     'gpk_trsm': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
+    'gpk_trsm_lz': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i]),
+    'gpk_gemm_lz': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i, _i]),
     'gpk_trsm_right_lt': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     'gpk_potrs': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     'gpk_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i]),
@@ -57,6 +59,7 @@ PROTOTYPES = {
     'gpk_gn_dims': (_i, [_pp, _pi, _pi]),
     'gpk_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _i, _vp, _pd, _pi]),
     'gpk_gn_build': (_i, [_vp, _pp, _vp, _vp, _i]),
+    'gpk_gn_build_rev': (_i, [_vp, _pp, _vp, _vp, _i]),
     'gpk_axpy': (_i, [_vp, _i, _d, _vp, _vp]),
     'gpk_gn_loss': (_i, [_vp, _pp, _vp, _vp, _pd]),
     'gpk_gn_hessian_grad': (_i, [_vp, _pp, _vp, _vp, _i, _vp, _i, _vp]),

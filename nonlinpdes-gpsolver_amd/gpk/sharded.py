@@ -103,11 +103,21 @@ class GpuBlockOps:
     def trsm_left(self, L, n, B, c0, ncols, trans=False):
         self.ctx._chk(self.lib.gpk_trsm(self.h, int(trans), self._p(L), n, L.stride(0), self._p(B, 0, c0), ncols, B.stride(0)))
 
+    def trsm_left_lz(self, L, n, B, c0, ncols, lead):
+        """forward solve on the columns [c0, c0+ncols) of B; column c < lead (global index) is zero above row lead-1-c"""
+        self.ctx._chk(self.lib.gpk_trsm_lz(self.h, self._p(L), n, L.stride(0), self._p(B, 0, c0), ncols, B.stride(0), int(lead - c0)))
+
+    def gram_tn_lz(self, Cm, cr, cc, m, n, k, A, ac, B, bc, lead):
+        """gram_tn with operand B's column c < lead (global index) zero above row lead-1-c"""
+        self.ctx._chk(self.lib.gpk_gemm_lz(self.h, 1, m, n, k, 1.0, self._p(A, 0, ac), A.stride(0), self._p(B, 0, bc), B.stride(0),
+                                           0.0, self._p(Cm, cr, cc), Cm.stride(0), int(lead - bc)))
+
     def trsv(self, L, n, x, trans):
         self.ctx._chk(self.lib.gpk_trsm(self.h, int(trans), self._p(L), n, L.stride(0), x.data_ptr(), 1, 1))
 
-    def gn_build(self, prob_struct, z, S):
-        self.ctx._chk(self.lib.gpk_gn_build(self.h, C.byref(prob_struct), z.data_ptr(), self._p(S), S.stride(0)))
+    def gn_build(self, prob_struct, z, S, rev=False):
+        fn = self.lib.gpk_gn_build_rev if rev else self.lib.gpk_gn_build
+        self.ctx._chk(fn(self.h, C.byref(prob_struct), z.data_ptr(), self._p(S), S.stride(0)))
 
     def axpy(self, n, alpha, x, y):
         self.ctx._chk(self.lib.gpk_axpy(self.h, n, float(alpha), x.data_ptr(), y.data_ptr()))
@@ -121,6 +131,7 @@ class ShardedFactorSolve:
     def __init__(self, ops, comm, nb=512):
         self.ops, self.comm, self.nb = ops, comm, int(nb)
         self.rank, self.P = comm.rank, comm.world
+        self.col_align = 128                                       # column shards start at multiples of this (tile/vector alignment)
         self._panel = None
 
     # ------------------------------------------------------------------------------------------------ Cholesky
@@ -169,23 +180,50 @@ class ShardedFactorSolve:
         c0 = min(self.rank * per, ncols)
         return c0, min(c0 + per, ncols), per
 
-    def gn_step(self, prob_struct, nz, rows, L, z, S, Hb, delta, step_size):
+    def column_ranges_lz(self, ncols, lead, rows):
+        """Contiguous column shards of equal WORK for the leading-zero right-hand side: column c < lead starts at row
+        lead-1-c, so its forward solve costs ~(rows - start)^2.  Returns the P+1 boundaries (multiples of 128)."""
+        import numpy as np
+        c = np.arange(ncols)
+        start = np.maximum(0, lead - 1 - c)
+        w = np.cumsum((rows - start).astype(np.float64) ** 2)
+        bounds = [0]
+        for r in range(1, self.P):
+            cut = int(np.searchsorted(w, w[-1] * r / self.P))
+            cut = min(max(_ceil_div(cut, self.col_align) * self.col_align, bounds[-1]), ncols)
+            bounds.append(cut)
+        bounds.append(ncols)
+        return bounds
+
+    def gn_step(self, prob_struct, nz, rows, L, z, S, Hb, delta, step_size, rev=False):
         """One Gauss-Newton step with S column-sharded and Hb row-block-sharded; z is updated identically on all ranks.
-        L: replicated factor (rows x rows); S: (rows, >= nz+1); Hb: (nz+1, >= nz+1); returns (loss_in, info)."""
+        L: replicated factor (rows x rows); S: (rows, >= nz+1); Hb: (nz+1, >= nz+1); returns (loss_in, info).
+        rev (elliptic system): unknown j lives in column nz-1-j of S, which makes column c zero above row nz-1-c; the
+        solves and products skip those zeros (28 % of the flops) and the column shards are cut by work, not by width."""
         ops, comm, P, rank, nb = self.ops, self.comm, self.P, self.rank, self.nb
         nc = nz + 1
-        ops.gn_build(prob_struct, z, S)                            # every rank writes all of [A | F] (a memset + O(N))
-        c0, c1, per = self.column_range(nc)
-        if c1 > c0:
-            ops.trsm_left(L, rows, S, c0, c1 - c0)                 # my columns of L^{-1}[A | F]
-        if P > 1:                                                  # all-gather the column shards of S
+        if rev:
+            ops.gn_build(prob_struct, z, S, rev=True)              # every rank writes all of [A | F] (a memset + O(N))
+            bounds = self.column_ranges_lz(nc, nz, rows)
+        else:
+            ops.gn_build(prob_struct, z, S)
+            per0 = _ceil_div(_ceil_div(nc, P), self.col_align) * self.col_align
+            bounds = [min(r * per0, nc) for r in range(P)] + [nc]
+        c0, c1 = bounds[rank], bounds[rank + 1]
+        per = max(bounds[r + 1] - bounds[r] for r in range(P))
+        if c1 > c0:                                                # my columns of L^{-1}[A | F]
+            if rev:
+                ops.trsm_left_lz(L, rows, S, c0, c1 - c0, nz)
+            else:
+                ops.trsm_left(L, rows, S, c0, c1 - c0)
+        if P > 1:                                                  # all-gather the column shards of S (padded to the widest)
             mine = torch.zeros((rows, per), dtype=torch.float64, device=S.device)
             if c1 > c0:
                 mine[:, :c1 - c0].copy_(S[:, c0:c1])
             parts = [torch.empty_like(mine) for _ in range(P)]
             comm.all_gather(parts, mine)
             for r in range(P):
-                a = min(r * per, nc); b = min(a + per, nc)
+                a, b = bounds[r], bounds[r + 1]
                 if r != rank and b > a:
                     S[:, a:b].copy_(parts[r][:, :b - a])
             del parts, mine
@@ -196,7 +234,10 @@ class ShardedFactorSolve:
                 continue
             i0 = i * nb
             ib = min(nb, nc - i0)
-            ops.gram_tn(Hb, i0, 0, ib, i0 + ib, rows, S, i0, S, 0)
+            if rev:
+                ops.gram_tn_lz(Hb, i0, 0, ib, i0 + ib, rows, S, i0, S, 0, nz)
+            else:
+                ops.gram_tn(Hb, i0, 0, ib, i0 + ib, rows, S, i0, S, 0)
         if P > 1:                                                  # all-gather the block rows (padded to equal counts)
             per_rank = _ceil_div(nblk, P)
             width = Hb.stride(0)
@@ -224,5 +265,7 @@ class ShardedFactorSolve:
         info = comm.max_int(info, Hb.device)
         delta.copy_(Hb[nz, :nz])
         ops.trsv(Hb, nz, delta, True)                              # replicated: L_H^{-T} y
+        if rev:
+            delta.copy_(torch.flip(delta, dims=[0]))               # back to the natural order of the unknowns
         ops.axpy(nz, -float(step_size), delta, z)
         return loss_in, info

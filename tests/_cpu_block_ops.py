@@ -40,14 +40,26 @@ class NumpyBlockOps:
     def trsv(self, L, n, x, trans):
         x.numpy()[:n] = solve_triangular(np.tril(L.numpy()[:n, :n]), x.numpy()[:n], lower=True, trans='T' if trans else 'N', check_finite=False)
 
-    def gn_build(self, prob_struct, z, S):
+    def gn_build(self, prob_struct, z, S, rev=False):
         s = S.numpy()
         s[:] = 0.0
         zz = z.numpy()
         A = self.sys.A(zz)[0]
         F = self.sys.F(zz)[0]
-        s[:A.shape[0], :A.shape[1]] = A
+        s[:A.shape[0], :A.shape[1]] = A[:, ::-1] if rev else A     # rev: unknown j in column nz-1-j
         s[:F.size, A.shape[1]] = F
+
+    # the leading-zero variants compute the same thing (the zeros are structural); the double also CHECKS the structure
+    def trsm_left_lz(self, L, n, B, c0, ncols, lead):
+        b = B.numpy()
+        for c in range(c0, min(c0 + ncols, lead)):
+            assert not np.any(b[:max(0, lead - 1 - c), c]), 'leading-zero structure violated'
+        self.trsm_left(L, n, B, c0, ncols)
+        for c in range(c0, min(c0 + ncols, lead)):
+            assert not np.any(b[:max(0, lead - 1 - c), c])
+
+    def gram_tn_lz(self, Cm, cr, cc, m, n, k, A, ac, B, bc, lead):
+        self.gram_tn(Cm, cr, cc, m, n, k, A, ac, B, bc)
 
     def axpy(self, n, alpha, x, y):
         y.numpy()[:n] += alpha * x.numpy()[:n]

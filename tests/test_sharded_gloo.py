@@ -65,6 +65,7 @@ def _worker(rank, world, port, case, out_dir):
             Theta = O.add_nugget(O.gram_matrix_assembly(Xd, Xb), 'Nonlinear_elliptic', Nd, Nb, 1e-6)[0]
             N, nz = 2 * Nd + Nb, Nd
             solver = ShardedFactorSolve(NumpyBlockOps(sysm), comm, nb=nb)
+            solver.col_align = 4                                  # small problem: let every rank own some columns
             Lt = torch.from_numpy(Theta.copy())
             assert solver.potrf(Lt, N) == 0
             z0 = rng.normal(size=nz)
@@ -72,15 +73,22 @@ def _worker(rank, world, port, case, out_dir):
             S = torch.zeros((N, nz + 4), dtype=torch.float64)
             Hb = torch.zeros((nz + 1, nz + 4), dtype=torch.float64)
             delta = torch.zeros(nz, dtype=torch.float64)
-            hist = []
-            for _ in range(3):
-                loss_in, info = solver.gn_step(None, nz, N, Lt, z, S, Hb, delta, 1.0)
-                assert info == 0
-                hist.append(loss_in)
             sol_ref, hist_ref = O.gn_method(sysm, [O.cholesky(Theta)], z0, 3, 1)
+            for rev in (False, True):                             # plain layout and the leading-zero (reversed) layout
+                z = torch.from_numpy(z0.copy())
+                hist = []
+                for _ in range(3):
+                    loss_in, info = solver.gn_step(None, nz, N, Lt, z, S, Hb, delta, 1.0, rev=rev)
+                    assert info == 0
+                    hist.append(loss_in)
+                np.testing.assert_allclose(hist, hist_ref[:3], rtol=1e-7)
+                assert np.linalg.norm(z.numpy() - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
             np.save(os.path.join(out_dir, f'gn_{rank}.npy'), z.numpy())
-            np.testing.assert_allclose(hist, hist_ref[:3], rtol=1e-7)
-            assert np.linalg.norm(z.numpy() - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
+            if case == 'gn':
+                b = solver.column_ranges_lz(nz + 1, nz, N)        # work-balanced shards: monotone, cover everything
+                assert b[0] == 0 and b[-1] == nz + 1 and all(b[i] < b[i + 1] for i in range(world))
+                widths = np.diff(b)
+                assert widths[0] > widths[-1]                     # early columns are cheap (long zero prefix): wider first shard
         dist.barrier()
     finally:
         dist.destroy_process_group()
