@@ -32,6 +32,8 @@ extern "C" int gpk_create(int device, gpk_handle* out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_info, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, 64 * sizeof(double));
     if (e == hipSuccess) e = hipMemset(h->d_info, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_obflags, 64 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(h->d_obflags, 0, 64 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_flags, (GPK_MAX_TRSV_BLOCKS + 1) * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->d_flags, 0, (GPK_MAX_TRSV_BLOCKS + 1) * sizeof(int));
     if (e != hipSuccess) { delete h; return -(int)e; }
@@ -49,6 +51,7 @@ extern "C" int gpk_destroy(gpk_handle h) {
     if (h->d_info) (void)hipFree(h->d_info);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
     if (h->d_flags) (void)hipFree(h->d_flags);
+    if (h->d_obflags) (void)hipFree(h->d_obflags);
     if (h->d_pts) (void)hipFree(h->d_pts);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);

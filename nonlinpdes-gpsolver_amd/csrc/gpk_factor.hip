@@ -43,6 +43,8 @@ __device__ __forceinline__ void load_rows(const double* __restrict__ P, long ld,
 __device__ unsigned long long gpk_dbg_stamps[16];
 #define GPK_STAMP(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 constexpr int RB = 16;          // register block
 constexpr int LB = 32;          // global loads kept in flight per staging round trip (a round trip costs ~1 us)
 constexpr int XS = NB + 1;      // odd stride: lane-per-row / lane-per-column accesses hit 64 distinct banks
@@ -52,6 +54,17 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane /* wave-unif
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
+}
+
+// Cross-workgroup data of the persistent kernels travels with agent-scope relaxed atomics (sc1 on gfx950: stores write
+// through to memory, loads bypass the XCD-private L2), so a hand-off needs no L2 write-back / invalidate fence.
+template <bool COH> __device__ __forceinline__ double ld_g(const double* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void st_g(double* p, double v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 
 // stage a <=64 x <=64 diagonal block into LDS (identity-padded): one round trip, each wave fetches 16 rows
@@ -134,12 +147,13 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
     return mask ? (int)__builtin_ctzll(mask) + 1 : 0;
 }
 
+template <bool COH = false>
 __device__ __forceinline__ void potf2_store(double* __restrict__ A, long lda, int n, const double* __restrict__ As) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
         const int r = wave * RB + u;
-        if (r < n && lane <= r) A[(long)r * lda + lane] = As[r * XS + lane];
+        if (r < n && lane <= r) st_g<COH>(A + (long)r * lda + lane, As[r * XS + lane]);
     }
 }
 
@@ -189,7 +203,7 @@ __device__ __forceinline__ void trsm_base_fetch(const double* __restrict__ B, lo
     }
 }
 
-template <bool TRANS, bool ROWVEC>
+template <bool TRANS, bool ROWVEC, bool COH = false>
 __device__ __forceinline__ void trsm_base_body(TrsmShared& sh, const double* __restrict__ L, long ldl, int nb,
                                                double* __restrict__ B, long ldb, int ncols, int blk, int dbg,
                                                const double (*pre)[RB] = nullptr) {
@@ -205,7 +219,7 @@ __device__ __forceinline__ void trsm_base_body(TrsmShared& sh, const double* __r
     {
         double tl[RB], tx[RB];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) tl[u] = L[(long)min(wave * RB + u, nb - 1) * ldl + lc];
+        for (int u = 0; u < RB; ++u) tl[u] = ld_g<COH>(L + (long)min(wave * RB + u, nb - 1) * ldl + lc);
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const int r = wave * RB + u;
@@ -267,7 +281,7 @@ __device__ __forceinline__ void trsm_base_body(TrsmShared& sh, const double* __r
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int r = wave * RB + u;
-                if (r < nr) B[(long)(c0 + r) * ldb + lane] = Ys[rho(lane) * XS + r];
+                if (r < nr) st_g<COH>(B + (long)(c0 + r) * ldb + lane, Ys[rho(lane) * XS + r]);
             }
         }
     } else {
@@ -325,6 +339,160 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     }
 }
 
+// ---- Cholesky of one outer block column (<= 512 columns, all rows below) in ONE persistent launch -----------------------
+// Workgroup r owns the 64-row block r of the block column.  For panel j = 0 .. J-1 (64 columns each):
+//   r == j : factor the diagonal tile (potf2_tile), write it back, raise flag D[j]; done.
+//   r >  j : wait for D[j]; X_r = A_rj L_jj^{-T} by substitution (trsm_base_body, the tile was fetched before the wait);
+//            raise X[r][j] if r < J (other row blocks need X_r as the column operand); then apply the rank-64 update of
+//            panel j to the tiles this workgroup still has to the right: A_rc -= X_r X_c^T, c = j+1 .. min(r, J-1), with
+//            X_c read from memory once flag X[c][j] is up (c == r: its own X, still in LDS).  MFMA, 32 x 32 per wave.
+// So the only thing between two diagonal factorisations is: flag hand-off, one 64 x 64 substitution and one tile
+// update in workgroup j+1 -- the rank-64 update launch (12.6 us) and the row solves of everybody else are off the chain.
+// A workgroup waits only for workgroups with a smaller blockIdx (dispatched earlier): no deadlock even when the grid
+// exceeds what is resident.  Flags carry the launch epoch (never cleared).  Tiles that cross workgroups (L_jj, X_c) are
+// stored write-through and loaded cache-bypassing (ld_g / st_g), so a hand-off costs a s_waitcnt, not an L2 write-back +
+// invalidate; a workgroup's own tiles stay in its XCD's L2, and the diagonal tile goes from the last update straight into
+// LDS for the factorisation.
+// MEASURED (round 1, tools/potrf_probe.py) and therefore OFF by default: 50-59 us per panel against 40-46 us for the
+// launch-per-panel path.  The chain workgroup runs wait (the owner's potf2, 17 us) -> substitution (13 us) -> tile
+// update (7.6 us) -> its own potf2 (17 us): the same latency-bound pieces, now strictly serial in one workgroup, whereas
+// the launch-per-panel path lets every workgroup start its copy of the factorisation at launch.  Kept (and covered by
+// tests/test_gpu_variants.py) as the scaffold for a version with a faster substitution.
+struct ObShared {
+    union {
+        struct { double As[NB * XS]; __attribute__((aligned(16))) double Ps[NB * RB]; } f;   // diagonal factorisation
+        TrsmShared t;                                                                       // substitution + own X (t.Ys)
+    } u;
+    __attribute__((aligned(16))) double Xc[NB * WS];                 // partner tile X_c, [n][k]
+};
+
+__device__ __forceinline__ bool ob_wait(const int* flag, int epoch) {
+    int it = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++it > (1 << 22)) return false;
+    }
+    return true;
+}
+
+// C (global, mr x nc valid) -= X_r X_c^T over kpad (multiple of 4) columns; X_r from t.Ys ([k][m], stride XS); X_c either
+// from Ys as well (OWN: the diagonal tile of this row block) or from Xc ([n][k], stride WS).
+// OUT = 0: store to memory; OUT = 1: keep the result in LDS (As, identity-padded) for the factorisation that follows.
+template <bool OWN, int OUT>
+__device__ __forceinline__ void ob_tile_update(double* __restrict__ Cg, long ldc, int mr, int nc, const double* __restrict__ Ys,
+                                               const double* __restrict__ Xc, int kpad, double* __restrict__ As) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm + 16 * i + lk + 4 * r, col = wn + 16 * j + li;
+                acc[i][j][r] = Cg[(long)min(row, mr - 1) * ldc + min(col, nc - 1)];
+            }
+    for (int ks = 0; ks < kpad; ks += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = -Ys[(ks + lk) * XS + wm + 16 * i + li];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = OWN ? Ys[(ks + lk) * XS + wn + 16 * j + li] : Xc[(wn + 16 * j + li) * WS + ks + lk];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm + 16 * i + lk + 4 * r, col = wn + 16 * j + li;
+                if (OUT == 1) As[row * XS + col] = (row < mr && col < nc) ? acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
+                else if (row < mr && col < nc) Cg[(long)row * ldc + col] = acc[i][j][r];
+            }
+}
+
+__global__ __launch_bounds__(256) void potrf_ob_kernel(double* __restrict__ A, long lda, int nrows, int ob, int* flags, int epoch,
+                                                       int* info, int pivot_base, int dbgs) {
+    __shared__ ObShared sh;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int J = (ob + NB - 1) / NB;
+    const int mr = min(NB, nrows - NB * r);                          // rows of this block
+    const int dbg = 0;
+#define OB_STAMP(i) do { if (dbgs && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
+    OB_STAMP(0);
+    bool ok = true;
+    bool staged = false;                                             // the (updated) diagonal tile already sits in LDS
+    for (int j = 0; j <= min(r, J - 1); ++j) {
+        const int nbj = min(NB, ob - NB * j);                        // width of panel j
+        double* const Tjj = A + (long)(NB * j) * lda + NB * j;
+        if (r == j) {
+            if (!staged) potf2_stage(Tjj, lda, nbj, sh.u.f.As);      // (only workgroup 0: nobody touched its tile)
+            __syncthreads();
+            OB_STAMP(5);
+            const int bad = potf2_tile(sh.u.f.As, sh.u.f.Ps, nbj);
+            OB_STAMP(6);
+            potf2_store<true>(Tjj, lda, nbj, sh.u.f.As);
+            if (bad && bad <= nbj && tid == 0) atomicCAS(info, 0, pivot_base + NB * j + bad);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = s_waitcnt: the write-through stores have landed
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&flags[8 * j + j], ok ? epoch : -epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            OB_STAMP(7);
+            break;
+        }
+        // ---- r > j: my tile of panel j, fetched before the wait
+        const int below = nrows - NB * (j + 1);
+        double* const Bj = Tjj + (long)nbj * lda;                    // first row below the diagonal tile (nbj = 64 whenever r > j exists)
+        double tx[RB];
+        trsm_base_fetch<true>(Bj, lda, nbj, below, r - j - 1, tx);
+        OB_STAMP(1);
+        if (tid == 0) ok = ob_wait(&flags[8 * j + j], epoch) && ok;
+        __syncthreads();
+        OB_STAMP(2);
+        trsm_base_body<false, true, true>(sh.u.t, Tjj, lda, nbj, Bj, lda, below, r - j - 1, dbg, &tx);   // X_r -> memory and t.Ys
+        if (r < J) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&flags[8 * j + r], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        OB_STAMP(3);
+        const int kpad = ((nbj + 3) / 4) * 4;
+        for (int c = j + 1; c <= min(r, J - 1); ++c) {
+            const int ncc = min(NB, ob - NB * c);                    // width of column block c
+            double* const Trc = A + (long)(NB * r) * lda + NB * c;
+            if (c == r) {
+                __syncthreads();
+                if (j + 1 == r) {                                    // next: this workgroup factors the tile -- keep it in LDS
+                    ob_tile_update<true, 1>(Trc, lda, mr, ncc, sh.u.t.Ys, nullptr, kpad, sh.u.f.As);
+                    staged = true;
+                } else {
+                    ob_tile_update<true, 0>(Trc, lda, mr, ncc, sh.u.t.Ys, nullptr, kpad, nullptr);
+                }
+            } else {
+                if (tid == 0) ok = ob_wait(&flags[8 * j + c], epoch) && ok;
+                __syncthreads();                                     // (also: the previous update has finished with Xc)
+                const double* Tcj = A + (long)(NB * c) * lda + NB * j;
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {                       // X_c: 64 rows x nbj columns, zero-padded in k
+                    const int n = (tid >> 6) * RB + u, k = tid & 63;
+                    const double v = ld_g<true>(Tcj + (long)n * lda + min(k, nbj - 1));
+                    sh.Xc[n * WS + k] = (k < nbj) ? v : 0.0;
+                }
+                __syncthreads();
+                ob_tile_update<false, 0>(Trc, lda, mr, ncc, sh.u.t.Ys, sh.Xc, kpad, nullptr);
+            }
+        }
+        __syncthreads();                                             // t.Ys / Xc are free again
+        OB_STAMP(4);
+    }
+    if (!ok && tid == 0) atomicCAS(info, 0, -1);                     // a bounded wait expired: cannot happen (see above)
+}
+
 // ---- forward substitution with a <=256-wide diagonal block, fused: one launch per 256-row strip ------------------------
 // L X = B for a diagonal block of up to SB = 256 rows; one workgroup (8 waves) owns SNC = 32 right-hand-side columns and
 // keeps its 256 x 32 slice of B in LDS for the whole solve.  The strip is walked in 16 blocks of 16 equations:
@@ -338,7 +506,6 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
 // Gauss-Newton TRSM took at N = 8400 (profiles/r01_*).  No inverse of a diagonal block is ever formed.
 // Measured (tools/strip_probe.py, n = 256, 4001 columns): 44 us per launch = ~5 us staging + 15 steps x ~2.4 us
 // (owner's tile update ~0.7 us, then its substitution ~0.8 us, both latency chains of one wave) + ~1 us store.
-typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int SB = 256, SNC = 32, SNT = 512;
 constexpr int SXS = SNC + 16;                                        // LDS row stride 48: rows k, k+1 are 128 B apart mod 256
 constexpr int SAS = 18;                                              // L tile row stride: operand reads hit 32 distinct bank pairs
@@ -667,6 +834,7 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
 
 int g_dbg = 0;
 int g_mt_trsm = 0;
+int g_persistent_ob = 0;                                             // gpk_debug_set key 7: 1 = persistent outer-block kernel (slower, see its header)
 int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
@@ -819,6 +987,14 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     constexpr int OB = 512;
     for (int k0 = 0; k0 < n; k0 += OB) {
         const int ob = (n - k0 < OB) ? n - k0 : OB;
+        if (g_persistent_ob) {
+            if (++h->ob_epoch == 0x7fffffff) {
+                GPK_HIP(h, hipMemsetAsync(h->d_obflags, 0, 64 * sizeof(int), h->stream));
+                h->ob_epoch = 1;
+            }
+            potrf_ob_kernel<<<gpk_ceil_div(n - k0, NB), 256, 0, h->stream>>>(A + (long)k0 * lda + k0, lda, n - k0, ob, h->d_obflags,
+                                                                              h->ob_epoch, h->d_info, pivot_base + k0, g_dbg);
+        } else
         for (int j0 = k0; j0 < k0 + ob; j0 += NB) {
             const int nb = (k0 + ob - j0 < NB) ? k0 + ob - j0 : NB;
             double* Ajj = A + (long)j0 * lda + j0;
@@ -901,6 +1077,7 @@ extern "C" int gpk_debug_set_mt_trsm(int v) { g_mt_trsm = v; return 0; }
 extern "C" int gpk_debug_set_strip(int v) { g_strip = v; return 0; }
 extern "C" int gpk_debug_set_fused_trsv(int v) { g_fused_trsv = v; return 0; }
 extern "C" int gpk_debug_set_fused_panel(int v) { g_fused_panel = v; return 0; }
+extern "C" int gpk_debug_set_persistent_ob(int v) { g_persistent_ob = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

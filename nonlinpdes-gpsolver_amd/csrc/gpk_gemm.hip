@@ -454,6 +454,7 @@ extern "C" int gpk_debug_set_mt_trsm(int v);
 extern "C" int gpk_debug_set_strip(int v);
 extern "C" int gpk_debug_set_fused_trsv(int v);
 extern "C" int gpk_debug_set_fused_panel(int v);
+extern "C" int gpk_debug_set_persistent_ob(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -461,6 +462,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 3) return gpk_debug_set_strip(value);
     if (key == 4) return gpk_debug_set_fused_trsv(value);
     if (key == 5) return gpk_debug_set_fused_panel(value);
+    if (key == 7) return gpk_debug_set_persistent_ob(value);
     if (key == 6) { g_supertile = value; return 0; }
     return GPK_ERR_ARG;
 }

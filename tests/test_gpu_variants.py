@@ -17,8 +17,9 @@ VARIANTS = [
     ('potf2 + trsm launches per Cholesky panel', {5: 0}),
     ('supertile schedule of the leading-zero SYRK', {6: 1}),
     ('128x128 GEMM tiles', {0: 1}),
+    ('persistent outer-block Cholesky kernel (flag-chained workgroups)', {7: 1}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
