@@ -35,7 +35,10 @@ def mean(rows, key):
     return sum(vals) / len(vals) if vals else None
 
 stats = one('stats/**/*kernel_stats.csv')
-if stats:
+if stats:                                                        # default command: config 2 + the sharded config 5 run
+    shutil.copy(stats, os.path.join(DST, f'{tag}_bench_full_kernel_stats.csv'))
+stats = one('stats_c2/**/*kernel_stats.csv')
+if stats:                                                        # --no-sharded-config: the value's workload alone
     shutil.copy(stats, os.path.join(DST, f'{tag}_bench_kernel_stats.csv'))
 for src, dst in [('bench.json', f'{tag}_bench.json'), ('bench_under_rocprof.json', f'{tag}_bench_under_rocprof.json')]:
     p = os.path.join(SRC, src)
