@@ -98,6 +98,7 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 }
 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
+int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
 int g_supertile = 0;                                                 // gpk_debug_set key 6: 1 = supertile schedule for the leading-zero SYRK (below)
 
 __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& tm, int& tn) {
@@ -324,9 +325,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 // C2) spend their time in dependent memory round trips, not in MFMAs: with the slab-by-slab pipeline above a 64x64
 // tile pays one ~3 us round trip per 16-deep slab plus one for the read-modify-write of C.  Here all four slabs of A
 // and B and the C tile are requested before anything is waited for: one round trip, one barrier, 64 MFMAs per wave.
-template <bool TA, bool TB>
+template <bool TA, bool TB, int BM>
 __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
-    constexpr int BM = 64, BN = 64, WM = 32, WN = 32, TM = 2, TN = 2, NK = 4;
+    constexpr int BN = 64, WM = BM / 2, WN = 32, TM = WM / 16, TN = 2, NK = 4;
     constexpr int A_SZ = TA ? BK * (BM + 16) : BM * (BK + 2);
     constexpr int B_SZ = TB ? BN * (BK + 2) : BK * (BN + 16);
     __shared__ __attribute__((aligned(16))) double smem[NK * (A_SZ + B_SZ)];
@@ -399,18 +400,27 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
         }
 }
 
-int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
-    g.ntm = gpk_ceil_div(g.M, 64);
+template <int BM>
+int launch_k64_bm(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
+    g.ntm = gpk_ceil_div(g.M, BM);
     g.ntn = gpk_ceil_div(g.N, 64);
     g.ntiles = g.ntm * g.ntn;
     g.nsuper = 0;
     dim3 grid(g.ntiles), block(256);
-    if (!ta && !tb) gemm_k64_kernel<false, false><<<grid, block, 0, h->stream>>>(g);
-    else if (!ta && tb) gemm_k64_kernel<false, true><<<grid, block, 0, h->stream>>>(g);
-    else if (ta && !tb) gemm_k64_kernel<true, false><<<grid, block, 0, h->stream>>>(g);
-    else gemm_k64_kernel<true, true><<<grid, block, 0, h->stream>>>(g);
+    if (!ta && !tb) gemm_k64_kernel<false, false, BM><<<grid, block, 0, h->stream>>>(g);
+    else if (!ta && tb) gemm_k64_kernel<false, true, BM><<<grid, block, 0, h->stream>>>(g);
+    else if (ta && !tb) gemm_k64_kernel<true, false, BM><<<grid, block, 0, h->stream>>>(g);
+    else gemm_k64_kernel<true, true, BM><<<grid, block, 0, h->stream>>>(g);
     GPK_LAUNCH_CHECK(h);
     return 0;
+}
+
+int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
+    // a rank-64 update is one round trip to memory plus 64 MFMAs per wave of a 64 x 64 tile: with fewer than ~4 tiles per
+    // CU, halving the tile spreads the MFMA phase over twice as many workgroups
+    const long t64 = (long)gpk_ceil_div(g.M, 64) * gpk_ceil_div(g.N, 64);
+    if (g_k64_small && t64 < 4 * h->num_cu && g.M > 64) return launch_k64_bm<32>(h, ta, tb, g);
+    return launch_k64_bm<64>(h, ta, tb, g);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -463,6 +473,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 4) return gpk_debug_set_fused_trsv(value);
     if (key == 5) return gpk_debug_set_fused_panel(value);
     if (key == 7) return gpk_debug_set_persistent_ob(value);
+    if (key == 8) { g_k64_small = value; return 0; }
     if (key == 6) { g_supertile = value; return 0; }
     return GPK_ERR_ARG;
 }
