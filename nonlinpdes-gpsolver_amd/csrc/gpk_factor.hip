@@ -90,54 +90,78 @@ __device__ __forceinline__ void potf2_stage(const double* __restrict__ A, long l
 // vector; after the barrier every thread subtracts l[r] * l[c] from the columns c > j it owns.  The chain per column
 // is pivot broadcast -> rsqrt -> LDS round trip -> one FMA; the previous version (16-column panels factored redundantly
 // by every wave with 2 x (15 - j) lane broadcasts per column, then a blocked update) spent ~680 cycles per column.
-__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 2 x NB doubles, 16-byte aligned */, int n) {
+__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 4 x NB doubles, 16-byte aligned */, int n) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int r = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // a[2k], a[2k+1]: columns 8 (o + k) + 2w, + 1 of row r, where o counts the finished groups of 8 columns -- the register
+    // file is ROTATED after every group so that the loop over groups can stay rolled with static register indices.
+    // (Fully unrolled, the 64 columns were 31 KB of straight-line code executed once per launch: instruction fetch,
+    // not arithmetic or LDS, set the pace -- 525 cycles per column however the arithmetic was arranged.)
     double a[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         a[2 * i] = As[r * XS + 8 * i + 2 * w];
         a[2 * i + 1] = As[r * XS + 8 * i + 2 * w + 1];
     }
+#pragma unroll 1
+    for (int o = 0; o < 8; ++o) {
+        const int jbase = 8 * o;
+        if (jbase >= n) break;
+        // Two columns per barrier: columns j, j+1 belong to the same wave (q), which finishes the first, applies it to the
+        // second in registers (one lane broadcast), finishes the second and publishes both; everybody then subtracts both
+        // rank-1 terms at once.  Lc holds 2 (parity of the pair) x 2 (column of the pair) vectors of NB doubles.
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j >= n) continue;                                        // (uniform; `break` would keep the loop rolled)
-        const int wo = (j >> 1) & 3, jr = 2 * (j >> 3) + (j & 1);
-        double* __restrict__ lc = Lc + (j & 1) * NB;
-        if (w == wo) {
-            const double d = bcast_lane(a[jr], j);                   // pivot lives in lane j
-            // 1/sqrt(d) and sqrt(d) by coupled Newton iterations from v_rsq_f64: g -> sqrt(d), hh -> 1/(2 sqrt(d))
-            const double y0 = __builtin_amdgcn_rsq(d);
-            double g = d * y0, hh = 0.5 * y0;
-            double e = fma(-g, hh, 0.5);
-            g = fma(g, e, g); hh = fma(hh, e, hh);
-            e = fma(-g, hh, 0.5);
-            g = fma(g, e, g); hh = fma(hh, e, hh);
-            const double sq = fma(fma(-g, g, d), hh, g);             // one more correction for the diagonal entry
-            const double v = (r == j) ? sq : a[jr] * (hh + hh);      // LAPACK dpotf2 also scales by the reciprocal
-            a[jr] = v;
-            lc[r] = v;
-        }
-        __syncthreads();
-        const double ml = lc[r];
+        for (int q = 0; q < 4; ++q) {
+            const int j = jbase + 2 * q;
+            if (j < n) {
+                double* __restrict__ lc0 = Lc + (q & 1) * 2 * NB;
+                double* __restrict__ lc1 = lc0 + NB;
+                if (w == q) {
+                    double v[2] = {0.0, 0.0};
 #pragma unroll
-        for (int i = j >> 3; i < 8; ++i) {
-            const d2 m = *reinterpret_cast<const d2*>(lc + 8 * i + 2 * w);
-            if (i == (j >> 3)) {                                     // the pair group that contains column j: mask c <= j
-                const int c0 = 8 * i + 2 * w;
-                a[2 * i] = (c0 > j) ? fma(-ml, m.x, a[2 * i]) : a[2 * i];       // select the RESULT: a NaN column must not
-                a[2 * i + 1] = (c0 + 1 > j) ? fma(-ml, m.y, a[2 * i + 1]) : a[2 * i + 1];   // reach finished columns (info)
-            } else {
-                a[2 * i] = fma(-ml, m.x, a[2 * i]);
-                a[2 * i + 1] = fma(-ml, m.y, a[2 * i + 1]);
+                    for (int t = 0; t < 2; ++t) {
+                        if (t == 1) {
+                            if (j + 1 >= n) break;
+                            a[1] = fma(-v[0], bcast_lane(v[0], j + 1), a[1]);   // times L[j+1][j]
+                        }
+                        const double d = bcast_lane(a[t], j + t);        // pivot lives in lane j + t
+                        // 1/sqrt(d), sqrt(d) by coupled Newton iterations from v_rsq_f64: g -> sqrt(d), hh -> 1/(2 sqrt(d))
+                        const double y0 = __builtin_amdgcn_rsq(d);
+                        double g = d * y0, hh = 0.5 * y0;
+                        double e = fma(-g, hh, 0.5);
+                        g = fma(g, e, g); hh = fma(hh, e, hh);
+                        e = fma(-g, hh, 0.5);
+                        g = fma(g, e, g); hh = fma(hh, e, hh);
+                        const double sq = fma(fma(-g, g, d), hh, g);     // one more correction for the diagonal entry
+                        v[t] = (r == j + t) ? sq : a[t] * (hh + hh);     // LAPACK dpotf2 also scales by the reciprocal
+                        a[t] = v[t];
+                    }
+                    lc0[r] = v[0];
+                    lc1[r] = v[1];
+                }
+                __syncthreads();
+                const double ml0 = lc0[r], ml1 = lc1[r];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k < 8 - o) {                                     // (uniform) groups that still exist
+                        const d2 m0 = *reinterpret_cast<const d2*>(lc0 + jbase + 8 * k + 2 * w);
+                        const d2 m1 = *reinterpret_cast<const d2*>(lc1 + jbase + 8 * k + 2 * w);
+                        const double u0 = fma(-ml1, m1.x, fma(-ml0, m0.x, a[2 * k]));
+                        const double u1 = fma(-ml1, m1.y, fma(-ml0, m0.y, a[2 * k + 1]));
+                        // in the group of the pair only the columns to the right of it (waves > q); the RESULT is selected,
+                        // so that a NaN column cannot reach finished columns (info)
+                        const bool take = (k > 0) || (w > q);
+                        a[2 * k] = take ? u0 : a[2 * k];
+                        a[2 * k + 1] = take ? u1 : a[2 * k + 1];
+                    }
+                }
             }
         }
-    }
+        As[r * XS + jbase + 2 * w] = a[0];                               // this group is final
+        As[r * XS + jbase + 2 * w + 1] = a[1];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        As[r * XS + 8 * i + 2 * w] = a[2 * i];
-        As[r * XS + 8 * i + 2 * w + 1] = a[2 * i + 1];
+        for (int k = 0; k < 14; ++k) a[k] = a[k + 2];
     }
     __syncthreads();
     // A non-positive (or NaN) pivot d gives rsqrt(d) = NaN or inf and a NaN on the diagonal, which then spreads: the
