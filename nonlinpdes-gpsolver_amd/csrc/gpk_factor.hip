@@ -96,8 +96,9 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // a[2k], a[2k+1]: columns 8 (o + k) + 2w, + 1 of row r, where o counts the finished groups of 8 columns -- the register
     // file is ROTATED after every group so that the loop over groups can stay rolled with static register indices.
-    // (Fully unrolled, the 64 columns were 31 KB of straight-line code executed once per launch: instruction fetch,
-    // not arithmetic or LDS, set the pace -- 525 cycles per column however the arithmetic was arranged.)
+    // (Fully unrolled, the 64 columns were 31 KB of straight-line code executed once per launch; rolled it is 8 KB.  The
+    // speed is the same, ~525 cycles per column = two rsqrt chains (~370 per pair) + LDS exchange and barrier (~250) +
+    // the rank-2 update of up to 16 register columns (~310): measured, tools/stamp_probe.py with GPK_DEBUG_SET=5=0.)
     double a[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
