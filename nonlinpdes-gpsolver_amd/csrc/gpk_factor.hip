@@ -519,163 +519,197 @@ __global__ __launch_bounds__(256) void potrf_ob_kernel(double* __restrict__ A, l
 }
 
 // ---- forward substitution with a <=256-wide diagonal block, fused: one launch per 256-row strip ------------------------
-// L X = B for a diagonal block of up to SB = 256 rows; one workgroup (8 waves) owns SNC = 32 right-hand-side columns and
-// keeps its 256 x 32 slice of B in LDS for the whole solve.  The strip is walked in 16 blocks of 16 equations:
-//   solve   : 16 x 16 triangular block by true substitution, lane = column, coefficients wave-uniform (scalar loads);
-//   update  : the row tiles below get  X_t -= L[t][s] X_s  on the matrix cores (v_mfma_f64_16x16x4_f64, K = 16); the
-//             wave that updates tile s+1 solves block s+1 right away and does nothing else in that step, the other seven
-//             waves share the tiles further down, so their updates overlap the (latency-bound) substitution;
-//   one barrier per step; the L tiles of step s+1 are fetched (clamped, branch-free) while step s runs.
-// This replaces, per 256 rows, four 64-row trsm_base launches (12.4 us each), two K=64, one K=128 GEMM launch and their
-// launch gaps: those levels of the recursion keep at most 126 workgroups busy anyway and cost 3.1 of the 6.5 ms the
-// Gauss-Newton TRSM took at N = 8400 (profiles/r01_*).  No inverse of a diagonal block is ever formed.
-// Measured (tools/strip_probe.py, n = 256, 4001 columns): 44 us per launch = ~5 us staging + 15 steps x ~2.4 us
-// (owner's tile update ~0.7 us, then its substitution ~0.8 us, both latency chains of one wave) + ~1 us store.
-constexpr int SB = 256, SNC = 32, SNT = 512;
-constexpr int SXS = SNC + 16;                                        // LDS row stride 48: rows k, k+1 are 128 B apart mod 256
-constexpr int SAS = 18;                                              // L tile row stride: operand reads hit 32 distinct bank pairs
+// L X = B for a diagonal block of up to SB = 256 rows; one workgroup (8 waves) owns SNC = 16 right-hand-side columns and
+// keeps its 256 x 16 slice of B in LDS for the whole solve.  The strip is walked in blocks of 8 equations:
+//   solve   : 8 x 8 triangular block by true substitution, lane = column; the 28 coefficients are wave-uniform and come
+//             through the scalar cache into SGPRs (all of them fit, so the loads are issued once, ahead of the chain);
+//   update  : the 16-row tiles below get  X_t -= L[t][b] X_b  on the matrix cores (v_mfma_f64_16x16x4_f64, K = 8); the
+//             wave that updates the tile holding block b+1 solves block b+1 right away and does nothing else in that
+//             step, the other seven waves share the tiles further down, so their updates overlap the substitution.  When
+//             block b+1 is the lower half of block b's own tile, that tile gets a half update (operand rows 0..7 zeroed).
+//   one barrier per step; the L tiles (16 x 8, one coalesced 16-byte load per lane) are fetched three steps ahead into
+//   registers and pass through a wave-private LDS tile to reach the MFMA operand layout.
+// Measured (tools/strip_probe.py, n = 256, 4001 columns): 37 us per launch = ~18 us skeleton (launch, staging round trip,
+// 31 barriers, store) + 5 us tile requests + 7 us substitutions + 8 us MFMA updates.  What the round-1 ablations found:
+//   * operand-layout loads straight from memory = 64 line accesses per instruction (3000 cycles per step) -> coalesced
+//     16-byte loads + a wave-private LDS transposition;
+//   * coefficients through s_load: scalar loads share lgkmcnt with LDS and return out of order, so every LDS wait of
+//     the chain became a scalar-memory wait -> 8 x 8 diagonal blocks staged in LDS once;
+//   * rotating prefetch registers with moves makes each step wait for the youngest load -> three sets used in rotation
+//     by unrolling, loads issued through inline asm with an explicit s_waitcnt vmcnt(6);
+//   * 32 columns per workgroup: the MFMA pipe of the one CU is the bound (126 workgroups) -> 16 columns (251 workgroups);
+//   * 512-row strips: 96 us, no better than two 256-row strips and the K = 256 update between them.
+// No inverse of a diagonal block is ever formed.
+constexpr int SB = 256, SNC = 16, SNT = 512;
+constexpr int NTL = (SB / 16 - 1 + 6) / 7;                            // row tiles per wave and step (the owner takes one, seven waves share the rest)
+constexpr int SCT = SNC / 16;                                        // 16-column MFMA tiles per workgroup
+constexpr int SXS = (SNC % 32 == 16) ? SNC : SNC + 16;               // LDS row stride: rows k, k+1 must be 128 B apart mod 256
+constexpr int SRPP = SNT / SNC;                                      // rows staged per pass
+constexpr int SAS = 10;                                              // L tile (16 x 8) row stride: operand reads conflict-free
 
 __global__ __launch_bounds__(SNT) void trsm_strip_kernel(const double* __restrict__ L, long ldl, int n,
                                                          double* __restrict__ B, long ldb, int ncols, int dbg) {
     GPK_STAMP(10);
+    typedef double d2 __attribute__((ext_vector_type(2)));
     __shared__ __attribute__((aligned(16))) double Xs[SB * SXS];
     __shared__ double rd[SB];                                        // 1 / diagonal
-    __shared__ __attribute__((aligned(16))) double At[(SNT / 64) * 2 * 16 * SAS];   // per wave: two 16x16 tiles of L
+    __shared__ __attribute__((aligned(16))) double Ld[SB * 8];       // the 8x8 diagonal blocks, Ld[64 blk + 8 j + i] = L[8 blk + j][8 blk + i]
+    __shared__ __attribute__((aligned(16))) double At[(SNT / 64) * NTL * 16 * SAS];   // per wave: NTL 16x8 tiles of L
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: role tests become scalar branches
     const int li = lane & 15, lk = lane >> 4;
     const int c0 = blockIdx.x * SNC;
-    const int nsteps = n >> 4;                                       // the host guarantees n % 16 == 0
+    const int nblocks = n >> 3, ntiles = n >> 4;                     // the host guarantees n % 16 == 0
 
-    // Roles in update step s (X_s solved, tiles t > s to be updated with it): wave (s+1) mod 8 owns tile s+1 and solves
-    // block s+1 right after updating it; the other seven waves take tiles s+1+j and s+8+j (j = their distance from the
-    // owner).  tiles_of() returns the two tiles of this wave (>= nsteps: none).
-    auto tiles_of = [wave](int s, int& t0, int& t1) {
-        const int j = (wave - (s + 1)) & 7;                          // 0 = owner
-        t0 = s + 1 + j;
-        t1 = j == 0 ? SB : s + 8 + j;
+    // Roles in update step b (X_b solved): tn = tile of block b+1; wave (tn mod 8) owns it; wave at distance j >= 1 from the
+    // owner takes tiles tn + j, tn + j + 7, ... (NTL of them; >= ntiles: none).
+    auto first_tile = [wave](int b) {
+        const int tn = (b + 1) >> 1;
+        const int j = (wave - tn) & 7;
+        return tn + j;                                               // j == 0: the owner's single tile
     };
-    // L tiles of the next step: fetched with coalesced 16-byte loads (8 lanes per 128-byte tile row; the MFMA A-operand
-    // layout itself puts adjacent lanes on different rows = 64 separate line accesses per load, which made the eight
-    // waves' tile loads alone cost ~3000 cycles per step), kept in registers for one step, then passed through a
-    // wave-private LDS tile to reach the operand layout.  Tile indices are clamped, so the loads are branch-free.
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    auto load_a = [&](int s, d2 (&a)[2][2]) {
-        const int sc = min(s, nsteps - 1);
-        int t[2];
-        tiles_of(sc, t[0], t[1]);
+    auto load_a = [&](int b, d2 (&a)[NTL]) {                         // clamped, branch-free
+        const int bc = min(b, nblocks - 1);
+        const int t0 = first_tile(bc);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double* __restrict__ p = L + (long)(16 * min(t[k], nsteps - 1) + (lane >> 3)) * ldl + 16 * sc + 2 * (lane & 7);
-            a[k][0] = *reinterpret_cast<const d2*>(p);
-            a[k][1] = *reinterpret_cast<const d2*>(p + 8 * ldl);
+        for (int k = 0; k < NTL; ++k) {
+            const int t = min(t0 + 7 * k, ntiles - 1);
+            const double* p = L + (long)(16 * t + (lane >> 2)) * ldl + 8 * bc + 2 * (lane & 3);
+            // issued through inline asm so that the s_waitcnt is OURS (vmcnt(6) before use: the two younger sets stay in
+            // flight); the compiler's own insertion fell back to vmcnt(0) across the loop's control flow
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[k]) : "v"(p) : "memory");
         }
     };
-    double* const at = At + wave * (2 * 16 * SAS);
-    auto to_operand = [&](const d2 (&a)[2][2], double (&op)[2][4]) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            double* __restrict__ w = at + k * 16 * SAS + (lane >> 3) * SAS + 2 * (lane & 7);
-            *reinterpret_cast<d2*>(w) = a[k][0];
-            *reinterpret_cast<d2*>(w + 8 * SAS) = a[k][1];
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) op[k][q] = at[k * 16 * SAS + li * SAS + 4 * q + lk];
+    static_assert(NTL == 3, "wait_set below names the registers of one set explicitly");
+    auto wait_set = [&](d2 (&a)[NTL]) {                              // the oldest set of the three outstanding ones has landed
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) :: "memory");
     };
-    d2 a0[2][2], a1[2][2];
-    load_a(0, a0);
+    double* const at = At + wave * (NTL * 16 * SAS);
+    d2 a0[NTL], a1[NTL], a2[NTL];
     {   // stage the slice of B (columns >= ncols as zeros) and the reciprocal diagonal: one round trip to memory
-        const int col = tid & 31, rb = tid >> 5;
+        const int col = tid % SNC, rb = tid / SNC;
         const int cc = min(c0 + col, ncols - 1);
-        double v[SB / 16];
+        double v[SB / SRPP];
 #pragma unroll
-        for (int i = 0; i < SB / 16; ++i) v[i] = B[(long)min(rb + 16 * i, n - 1) * ldb + cc];
-        const double dg = L[(long)min(tid, n - 1) * (ldl + 1)];
+        for (int i = 0; i < SB / SRPP; ++i) v[i] = B[(long)min(rb + SRPP * i, n - 1) * ldb + cc];
+        // row (tid) of its 8x8 diagonal block: 64 contiguous bytes per thread.  (Coefficients as LDS broadcasts, not
+        // scalar loads: s_load shares the lgkmcnt counter with LDS and returns out of order, so with scalar loads in
+        // flight every LDS wait of the chain became a wait for scalar-memory latency.)
+        d2 dr[4];
+        const int rr = min(tid, n - 1);
 #pragma unroll
-        for (int i = 0; i < SB / 16; ++i) Xs[(rb + 16 * i) * SXS + col] = (rb + 16 * i < n && c0 + col < ncols) ? v[i] : 0.0;
-        if (tid < SB) rd[tid] = 1.0 / dg;
+        for (int i = 0; i < 4; ++i) dr[i] = *reinterpret_cast<const d2*>(L + (long)rr * ldl + (rr & ~7) + 2 * i);
+#pragma unroll
+        for (int i = 0; i < SB / SRPP; ++i) Xs[(rb + SRPP * i) * SXS + col] = (rb + SRPP * i < n && c0 + col < ncols) ? v[i] : 0.0;
+        if (tid < SB) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<d2*>(Ld + 8 * tid + 2 * i) = dr[i];
+            const int jj = tid & 7;
+            double dg = dr[0].x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (i == jj) dg = (i & 1) ? dr[i >> 1].y : dr[i >> 1].x;
+            rd[tid] = 1.0 / dg;
+        }
     }
     __syncthreads();
+    // (the compiler has waited for every load of its own above: from here on the only vector-memory operations in flight
+    // are the tile requests below, three per step, consumed in order)
+    load_a(0, a0); load_a(1, a1); load_a(2, a2);
     GPK_STAMP(11);
 
-    // 16 x 16 substitution, lane = column (lanes 32..63 mirror lanes 0..31).  The coefficients are wave-uniform and come
-    // straight from L through the scalar cache (s_load into SGPRs, an SGPR operand per v_fma_f64): broadcasting them
-    // from LDS made the 120 ds_reads the bottleneck of the whole kernel (2900 cycles per block, round 1 stamps).
-    auto solve = [&](int s) {
-        const int col = lane & 31;
-        double* __restrict__ xp = Xs + 16 * s * SXS + col;
-        const double* __restrict__ Ls = L + (long)(16 * s) * (ldl + 1);
-        double x[16];
+    auto solve = [&](int b) {                                        // lanes 32..63 mirror lanes 0..31
+        const int col = lane % SNC;
+        double* __restrict__ xp = Xs + 8 * b * SXS + col;
+        const double* __restrict__ Ls = Ld + 64 * b;
+        double x[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x[j] = xp[j * SXS];
+        for (int j = 0; j < 8; ++j) x[j] = xp[j * SXS];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < 8; ++j) {
             double e = x[j], o = 0.0;
 #pragma unroll
             for (int i = 0; i < j; ++i) {
-                if (i & 1) o = fma(-Ls[(long)j * ldl + i], x[i], o);
-                else       e = fma(-Ls[(long)j * ldl + i], x[i], e);
+                if (i & 1) o = fma(-Ls[8 * j + i], x[i], o);
+                else       e = fma(-Ls[8 * j + i], x[i], e);
             }
-            x[j] = (e + o) * rd[16 * s + j];
+            x[j] = (e + o) * rd[8 * b + j];
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) xp[j * SXS] = x[j];
+        for (int j = 0; j < 8; ++j) xp[j * SXS] = x[j];
     };
-    auto update = [&](int s, int t, const double (&a)[4], const double (&nb)[2][4]) {
-        double* __restrict__ xt = Xs + (16 * t + lk) * SXS + li;
-        d4 acc[2];
+    // tile t -= L[t][b] * X_b; `half`: only rows 8..15 of the tile (the tile is block b's own)
+    auto update = [&](int t, int slot, const double (&nb)[SCT][2], bool half) {
+        double a[2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int q = 0; q < 2; ++q) {
+            const double v = at[slot * 16 * SAS + li * SAS + 4 * q + lk];
+            a[q] = (half && li < 8) ? 0.0 : v;
+        }
+        double* __restrict__ xt = Xs + (16 * t + lk) * SXS + li;
+        d4 acc[SCT];
+#pragma unroll
+        for (int c = 0; c < SCT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[c][r] = xt[4 * r * SXS + 16 * c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nb[c][q], acc[c], 0, 0, 0);
+            for (int c = 0; c < SCT; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], nb[c][q], acc[c], 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < SCT; ++c)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xt[4 * r * SXS + 16 * c] = acc[c][r];
     };
-    auto step = [&](int s, const d2 (&ar)[2][2]) {
-        int t0, t1;
-        tiles_of(s, t0, t1);
-        if (t0 < nsteps) {
-            double a[2][4];
-            to_operand(ar, a);
-            double nb[2][4];                                         // -X_s in MFMA B-operand layout: B[k = 4q + lk][n = li]
-            const double* __restrict__ xs = Xs + (16 * s + lk) * SXS + li;
+
+    // One step.  `au` holds this step's L tiles (requested three steps ago); they go to the wave-private LDS tile first and
+    // the same registers immediately take the request for step b+3 -- three register sets used in rotation by unrolling,
+    // NOT by moving values between sets (a move would have to wait for the youngest load: that alone made every step
+    // cost a full memory round trip, ~2900 cycles).
+    auto step = [&](int b, d2 (&au)[NTL]) {
+        wait_set(au);
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+        for (int k = 0; k < NTL; ++k)
+            *reinterpret_cast<d2*>(at + k * 16 * SAS + (lane >> 2) * SAS + 2 * (lane & 3)) = au[k];
+        load_a(b + 3, au);
+        const int tn = (b + 1) >> 1;                                 // tile of the next block
+        const int t0 = first_tile(b);
+        if (t0 < ntiles) {
+            double nb[SCT][2];                                       // -X_b in MFMA B-operand layout: B[k = 4q + lk][n = li]
+            const double* __restrict__ xs = Xs + (8 * b + lk) * SXS + li;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) nb[c][q] = -xs[4 * q * SXS + 16 * c];
-            update(s, t0, a[0], nb);
-            if (t0 == s + 1) solve(t0);                              // this wave owns the next diagonal block
-            else if (t1 < nsteps) update(s, t1, a[1], nb);
+            for (int c = 0; c < SCT; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) nb[c][q] = -xs[4 * q * SXS + 16 * c];
+            update(t0, 0, nb, t0 == (b >> 1));
+            if (t0 == tn) {
+                solve(b + 1);                                        // this wave owns the next diagonal block
+            } else {
+#pragma unroll
+                for (int k = 1; k < NTL; ++k)
+                    if (t0 + 7 * k < ntiles) update(t0 + 7 * k, k, nb, false);
+            }
         }
         __syncthreads();
     };
-
     if (wave == 0) solve(0);
     __syncthreads();
     GPK_STAMP(12);
-    for (int s = 0; s < nsteps - 1; s += 2) {
-        load_a(s + 1, a1);
-        step(s, a0);
-        if (s == 0) GPK_STAMP(13);
-        if (s + 1 >= nsteps - 1) break;
-        load_a(s + 2, a0);
-        step(s + 1, a1);
+    for (int b = 0; b < nblocks - 1; b += 3) {
+        step(b, a0);
+        if (b == 0) GPK_STAMP(13);
+        if (b + 1 >= nblocks - 1) break;
+        step(b + 1, a1);
+        if (b + 2 >= nblocks - 1) break;
+        step(b + 2, a2);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // drain the clamped tail requests
     GPK_STAMP(14);
     {
-        const int col = tid & 31, rb = tid >> 5;
+        const int col = tid % SNC, rb = tid / SNC;
         if (c0 + col < ncols) {
 #pragma unroll
-            for (int i = 0; i < SB / 16; ++i)
-                if (rb + 16 * i < n) B[(long)(rb + 16 * i) * ldb + c0 + col] = Xs[(rb + 16 * i) * SXS + col];
+            for (int i = 0; i < SB / SRPP; ++i)
+                if (rb + SRPP * i < n) B[(long)(rb + SRPP * i) * ldb + c0 + col] = Xs[(rb + SRPP * i) * SXS + col];
         }
     }
     GPK_STAMP(15);
