@@ -355,8 +355,9 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dist.init_process_group('nccl')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group(os.environ.get('GPK_BENCH_BACKEND', 'nccl'))   # (gloo only in the CPU flow test)
     workload = args.workload if args.workload != 'auto' else 'c2'
     if args.sharded_path or workload == 'c5':
         out = run_sharded(args, workload)

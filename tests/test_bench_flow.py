@@ -1,0 +1,56 @@
+"""Control flow of bench.py with N > 1 ranks, on CPU: two gloo processes, the GPU-touching functions replaced by stubs.
+Checks what the driver relies on: every rank takes part in both phases (replicas of config 2, then the sharded config 5),
+exactly ONE JSON line comes out (rank 0), it carries n_gpus, the weak-scaling value of the replicas and the sharded run
+under sharded_config."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_two_rank_flow_prints_one_line(tmp_path):
+    script = tmp_path / 'drive.py'
+    script.write_text(textwrap.dedent(f'''
+        import os, sys
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'nonlinpdes-gpsolver_amd'))
+        import bench
+        def fake_single(args, workload, comm=None):
+            assert workload == 'c2' and comm is not None and comm.world == 2
+            comm.barrier()
+            t = comm.max_float(0.5 + comm.rank, 'cpu')           # slowest rank counts
+            out = {{'metric': 'm', 'value': comm.world * args.steps / t, 'n_gpus': comm.world, 'scaling': 'weak', 'steps': args.steps}}
+            return out if comm.rank == 0 else None
+        def fake_sharded(args, workload, steps=None, warmup=None):
+            assert workload == 'c5' and steps == min(args.steps, 3) and warmup == 1
+            import torch.distributed as dist
+            dist.barrier()
+            if dist.get_rank() != 0:
+                return None
+            return {{k: 1 for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'config', 'l2_error',
+                                   'f1_tflops', 'one_time_ms', 'roofline')}}
+        bench.run_single, bench.run_sharded = fake_single, fake_sharded
+        sys.argv = ['bench.py', '--gpus', '2', '--steps', '4', '--warmup', '1']
+        bench.main()
+    '''))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), GPK_BENCH_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines = [l for o in outs for l in o[0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
+    assert abs(d['value'] - 2 * 4 / 1.5) < 1e-9                  # max over ranks of (0.5, 1.5)
+    assert d['sharded_config']['n_gpus'] == 1 and 'roofline' in d['sharded_config']
