@@ -754,9 +754,9 @@ __global__ __launch_bounds__(64) void trsv_diag_kernel(const double* __restrict_
 // flags never need clearing), then solves its diagonal block by substitution (one wave, lane = equation) and publishes
 // x_w.  A workgroup only ever waits for workgroups with a smaller blockIdx, which the hardware dispatches first, so the
 // wait chain cannot deadlock; the spin is bounded anyway and poisons the result with NaN if it ever expires.
-// Visibility across the eight XCD-private L2s: x_w is stored with agent-scope atomic stores and followed by an
-// agent-scope release fence before the flag store; readers acquire on the flag and read x_d with agent-scope atomic
-// loads.  The 64 x 64 coefficient tiles are single-use and prefetched one dependency ahead, independent of the flags.
+// Visibility across the eight XCD-private L2s: x_w is stored with agent-scope atomic stores (write-through) and the
+// flag store follows once they have landed (s_waitcnt); readers poll the flag and read x_d with agent-scope atomic loads
+// (cache-bypassing) -- no L2 write-back / invalidate fence on the chain.  The 64 x 64 coefficient tiles are single-use and prefetched one dependency ahead, independent of the flags.
 // Measured: 329 us for n = 4000 backward (5.2 us per link of the chain: release, flag visibility, poll, acquire, the
 // x_d loads, 64 substitution steps).  Tried and slower: the chain on a single XCD (tile stream on 32 CUs only, 698 us);
 // four dependencies per round trip (serial flag polls, 449 us).
@@ -809,8 +809,7 @@ __global__ __launch_bounds__(256) void trsv_fused_kernel(const double* __restric
                 if (++it > (1 << 22)) { dead = true; break; }
             }
         }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();                                             // (x_d is read with cache-bypassing loads: no acquire fence)
         const int c0 = dbid * NB, cnb = min(NB, n - c0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -844,7 +843,7 @@ __global__ __launch_bounds__(256) void trsv_fused_kernel(const double* __restric
         }
         if (__builtin_amdgcn_readfirstlane((int)dead)) res = __builtin_nan("");
         if (r < nb) __hip_atomic_store(&x[r0 + r], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // = s_waitcnt: the write-through stores have landed
         if (r == 0) __hip_atomic_store(&flags[bid], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
