@@ -7,64 +7,44 @@ import argparse
 
 import numpy as onp
 
-from _driver_common import add_gn_and_logs, add_kernel_and_sampling, figures_enabled
-from src.solver import solver_GP
+from _driver_common import add_gn_and_logs, add_kernel_and_sampling, report_test_error, solve_forward, tensor_grid
+
+UNIT_SQUARE = [[0, 1], [0, 1]]
 
 
-def get_parser():
+def parse(argv=None):
     parser = argparse.ArgumentParser(description='NonLinElliptic equation GP solver')
     parser.add_argument("--alpha", type=float, default=1.0)
     parser.add_argument("--m", type=float, default=3.0)
     add_kernel_and_sampling(parser, 'Gaussian', 0.2, 1e-13, 900, 124)
     parser.add_argument("--pen_lambda", type=float, default=1e-10)      # for the relaxation approach
     add_gn_and_logs(parser, 'rdm', 4, method_choices=['elimination', 'relaxation'])
-    return parser.parse_args()
+    return parser.parse_args(argv)
 
 
-cfg = get_parser()
-show = figures_enabled(cfg)
+def manufactured(alpha, m):
+    """u* = sin(pi x1) sin(pi x2) + 2 sin(4 pi x1) sin(4 pi x2) and f = -Laplace(u*) + alpha u*^m"""
+    pi = onp.pi
 
-##### step 0: initialize the solver
-solver = solver_GP(cfg, PDE_type="Nonlinear_elliptic")
+    def u(x1, x2):
+        return onp.sin(pi * x1) * onp.sin(pi * x2) + 2 * onp.sin(4 * pi * x1) * onp.sin(4 * pi * x2)
 
-##### step 1: set the equation, rhs, bdy
-alpha, m = cfg.alpha, cfg.m
-pi = onp.pi
-
-
-def u(x1, x2):
-    return onp.sin(pi * x1) * onp.sin(pi * x2) + 2 * onp.sin(4 * pi * x1) * onp.sin(4 * pi * x2)
+    def f(x1, x2):
+        lap = -2 * pi ** 2 * onp.sin(pi * x1) * onp.sin(pi * x2) - 64 * pi ** 2 * onp.sin(4 * pi * x1) * onp.sin(4 * pi * x2)
+        return -lap + alpha * (u(x1, x2) ** m)
+    return u, f
 
 
-def f(x1, x2):          # -Laplace(u) + alpha*u^m
-    return 2 * pi ** 2 * onp.sin(pi * x1) * onp.sin(pi * x2) + 64 * pi ** 2 * onp.sin(4 * pi * x1) * onp.sin(4 * pi * x2) \
-        + alpha * (u(x1, x2) ** m)
+def main(argv=None):
+    cfg = parse(argv)
+    u, f = manufactured(cfg.alpha, cfg.m)
+    solver, show = solve_forward(cfg, "Nonlinear_elliptic", u, f, UNIT_SQUARE,
+                                 solve_kwargs={'method': cfg.method, 'pen_lambda': cfg.pen_lambda}, verbose=cfg.print_hist)
+    Xd = solver.eqn.X_domain
+    solver.collocation_pts_err(u(Xd[:, 0], Xd[:, 1]))                    # error on the collocation points
+    XX, YY, X_test = tensor_grid(60, *UNIT_SQUARE)                       # error on a 60 x 60 test grid
+    report_test_error(solver, show, XX, YY, X_test, u(X_test[:, 0], X_test[:, 1]))
 
 
-solver.set_equation(bdy=u, rhs=f, domain=onp.array([[0, 1], [0, 1]]), print_option=cfg.print_hist)
-
-##### step 2: sample points
-solver.auto_sample(cfg.N_domain, cfg.N_boundary, sampled_type=cfg.sampled_type, print_option=cfg.print_hist)
-if show:
-    solver.show_sample()
-
-##### step 3: solve the equation using GP + GN iterations
-solver.solve(method=cfg.method, pen_lambda=cfg.pen_lambda, print_option=cfg.print_hist)
-if show:
-    solver.show_loss_hist()
-
-##### step 4: error calculation on training points
-pts_truth = u(solver.eqn.X_domain[:, 0], solver.eqn.X_domain[:, 1])
-solver.collocation_pts_err(pts_truth)
-
-##### step 5: error calculation on test points
-N_pts = 60
-xx = onp.linspace(0, 1, N_pts)
-yy = onp.linspace(0, 1, N_pts)
-XX, YY = onp.meshgrid(xx, yy)
-X_test = onp.concatenate((XX.reshape(-1, 1), YY.reshape(-1, 1)), axis=1)
-test_truth = u(X_test[:, 0], X_test[:, 1])
-solver.test(X_test)
-solver.get_test_error(test_truth)
-if show:
-    solver.contour_of_test_err(XX, YY)
+if __name__ == '__main__':
+    main()

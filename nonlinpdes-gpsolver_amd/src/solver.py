@@ -26,13 +26,47 @@ _EQUATIONS = {
 }
 
 
-def _plt():
-    import matplotlib
-    import matplotlib.pyplot as plt
-    return plt
+# every bracket-tagged log line of the facade, keyed by event (texts are the reference's, src/solver.py:41-206)
+_LOG = {
+    'start': '\n Solver started',
+    'domain': '[Equation domain] [{d[0][0]},{d[0][1]}]*[{d[1][0]},{d[1][1]}]',
+    'data': '[Equation data] Right hand side and boundary values set by the user',
+    'pts_user': '[Sample points] Collocation points sampled, specified by the user',
+    'pts_auto': '[Sample points] Collocation points sampled, type {kind}',
+    'pts_n': '[Sample points] N_domain = {e.N_domain}, N_boundary = {e.N_boundary}',
+    'pts_n_ip': '[Sample points] N_domain = {e.N_domain}, N_boundary = {e.N_boundary}, N_data = {e.N_data}',
+    'obs': '[Observed Data] Get observed data from solving the PDE using FD and interpolation',
+    'obs_noise': '[Observed Data] Noise level {noise}',
+    'kernel': '[Kernel] {c.kernel}',
+    'kernel_par': '[Kernel parameter]: {c.kernel_parameter}',
+    'gram': '[Gram matrix] Finish assembly of the Gram matrix, nugget {c.nugget}, type {c.nugget_type}',
+    'chol': '[Gram matrix] Finish Cholesky factorization of the Gram matrix',
+    'gn_start': '[Gauss Newton] Start Gauss Newton iteration',
+    'gn_method': '[Gauss Newton] {method} approaches',
+    'gn_done': '[Gauss Newton] Gauss Newton iteration finished',
+    'pts_err': '[Calculating collocation errors...]',
+    'pts_max': '[Collocation point error] Max error {v}',
+    'pts_l2': '[Collocation point error] L2 error {v}',
+    'testing': '[Testing...] Number of test points: {n}',
+    'test_max': '[Test error] Max error {v}',
+    'test_l2': '[Test error] L2 error {v}',
+}
+
+
+def _say(enabled, *keys, **fmt):
+    if enabled:
+        for k in keys:
+            print(_LOG[k].format(**fmt))
+
+
+def _rms_over(err, count):
+    return onp.sqrt(onp.sum(err ** 2) / count)
 
 
 class solver_GP(object):
+    """Same public surface as the reference's solver_GP; the work happens in the equation objects (src/PDEs.py,
+    src/InverseProblems.py), which drive libgpk."""
+
     def __init__(self, cfg=None, PDE_type="Nonlinear_elliptic"):
         self.config = cfg
         self.PDE_type = PDE_type
@@ -43,130 +77,86 @@ class solver_GP(object):
         make, header, params = _EQUATIONS[self.PDE_type]
         self.eqn = make(self.config, bdy=bdy, rhs=rhs, domain=domain)
         if print_option:
-            print('\n Solver started')
+            print(_LOG['start'])
             for line in header(self.config):
                 print(line)
-            print(f'[Equation domain] [{domain[0,0]},{domain[0,1]}]*[{domain[1,0]},{domain[1,1]}]')
+            _say(True, 'domain', d=domain)
             if params is not None:
                 print(params(self.config))
-            print('[Equation data] Right hand side and boundary values set by the user')
+            _say(True, 'data')
 
-    # ---- sampling ------------------------------------------------------------------------------------------------------
+    # ---- collocation (and data) points: given by the caller or drawn by the equation object's sampler -------------------
     def get_sample(self, X_domain, X_boundary, print_option=True):
         # (the reference passes `self` twice here and raises TypeError; this one works)
         self.eqn.get_sampled_points(X_domain, X_boundary)
-        if print_option:
-            print('[Sample points] Collocation points sampled, specified by the user')
-            print(f'[Sample points] N_domain = {self.eqn.N_domain}, N_boundary = {self.eqn.N_boundary}')
+        _say(print_option, 'pts_user', 'pts_n', e=self.eqn)
 
     def auto_sample(self, N_domain, N_boundary, sampled_type='random', print_option=True):
         self.eqn.sampled_pts(N_domain, N_boundary, sampled_type=sampled_type)
-        if print_option:
-            print(f'[Sample points] Collocation points sampled, type {sampled_type}')
-            print(f'[Sample points] N_domain = {self.eqn.N_domain}, N_boundary = {self.eqn.N_boundary}')
+        _say(print_option, 'pts_auto', 'pts_n', e=self.eqn, kind=sampled_type)
 
     def get_sample_IP(self, X_domain, X_boundary, X_data, print_option=True):
         self.eqn.get_sampled_points(X_domain, X_boundary, X_data)
-        if print_option:
-            print('[Sample points] Collocation points sampled, specified by the user')
-            print(f'[Sample points] N_domain = {self.eqn.N_domain}, N_boundary = {self.eqn.N_boundary}, N_data = {self.eqn.N_data}')
+        _say(print_option, 'pts_user', 'pts_n_ip', e=self.eqn)
 
     def auto_sample_IP(self, N_domain, N_boundary, N_data, sampled_type='random', print_option=True):
         self.eqn.sampled_pts(N_domain, N_boundary, N_data, sampled_type=sampled_type)
-        if print_option:
-            print(f'[Sample points] Collocation points sampled, type {sampled_type}')
-            print(f'[Sample points] N_domain = {self.eqn.N_domain}, N_boundary = {self.eqn.N_boundary}, N_data = {self.eqn.N_data}')
+        _say(print_option, 'pts_auto', 'pts_n_ip', e=self.eqn, kind=sampled_type)
 
     def get_observed_data(self, data_u, noise_level, print_option=True):
         self.eqn.get_observation(data_u, noise_level)
-        if print_option:
-            print('[Observed Data] Get observed data from solving the PDE using FD and interpolation')
-            print(f'[Observed Data] Noise level {noise_level}')
+        _say(print_option, 'obs', 'obs_noise', noise=noise_level)
 
-    # ---- solve ---------------------------------------------------------------------------------------------------------
+    # ---- Gram matrix -> Cholesky -> Gauss-Newton -------------------------------------------------------------------------
     def solve(self, method='elimination', pen_lambda=1e-10, print_option=True):
-        c = self.config
-        if print_option:
-            print('[Kernel] ' + c.kernel)
-            print(f'[Kernel parameter]: {c.kernel_parameter}')
-        self.eqn.Gram_matrix(kernel=c.kernel, kernel_parameter=c.kernel_parameter, nugget=c.nugget, nugget_type=c.nugget_type)
-        if print_option:
-            print(f'[Gram matrix] Finish assembly of the Gram matrix, nugget {c.nugget}, type {c.nugget_type}')
-        self.eqn.Gram_Cholesky()
-        if print_option:
-            print('[Gram matrix] Finish Cholesky factorization of the Gram matrix')
-            print('[Gauss Newton] Start Gauss Newton iteration')
-            print(f'[Gauss Newton] {method} approaches')
+        c, eqn = self.config, self.eqn
+        _say(print_option, 'kernel', 'kernel_par', c=c)
+        eqn.Gram_matrix(kernel=c.kernel, kernel_parameter=c.kernel_parameter, nugget=c.nugget, nugget_type=c.nugget_type)
+        _say(print_option, 'gram', c=c)
+        eqn.Gram_Cholesky()
+        _say(print_option, 'chol', 'gn_start', 'gn_method', method=method)
+        gn = dict(max_iter=c.GNsteps, step_size=c.step_size, initial_sol=c.initial_sol, print_hist=c.print_hist)
         if method == 'elimination':
-            self.eqn.GN_method(max_iter=c.GNsteps, step_size=c.step_size, initial_sol=c.initial_sol, print_hist=c.print_hist)
+            eqn.GN_method(**gn)
         elif method == 'relaxation':
-            self.eqn.GN_relaxed_method(max_iter=c.GNsteps, step_size=c.step_size, initial_sol=c.initial_sol,
-                                       pen_lambda=pen_lambda, print_hist=c.print_hist)
-        if print_option:
-            print('[Gauss Newton] Gauss Newton iteration finished')
+            eqn.GN_relaxed_method(pen_lambda=pen_lambda, **gn)
+        _say(print_option, 'gn_done')
 
-    # ---- errors --------------------------------------------------------------------------------------------------------
+    # ---- errors (definitions of src/solver.py:175,191: root of the sum of squares over N_domain / N_test) ----------------
     def collocation_pts_err(self, truth, print_option=True):
-        if print_option:
-            print('[Calculating collocation errors...]')
+        _say(print_option, 'pts_err')
         self.pts_err_all = abs(onp.asarray(truth) - self.eqn.sol_sampled_pts)
         self.pts_max_err = onp.max(self.pts_err_all)
-        self.pts_L2_err = onp.sqrt(onp.sum(self.pts_err_all ** 2) / (self.eqn.N_domain))
-        if print_option:
-            print(f'[Collocation point error] Max error {self.pts_max_err}')
-            print(f'[Collocation point error] L2 error {self.pts_L2_err}')
+        self.pts_L2_err = _rms_over(self.pts_err_all, self.eqn.N_domain)
+        _say(print_option, 'pts_max', v=self.pts_max_err)
+        _say(print_option, 'pts_l2', v=self.pts_L2_err)
 
     def test(self, X_test, print_option=True):
-        if print_option:
-            print(f'[Testing...] Number of test points: {X_test.shape[0]}')
+        _say(print_option, 'testing', n=X_test.shape[0])
         self.eqn.extend_sol(X_test)
 
     def get_test_error(self, truth, print_option=True):
         self.truth = truth
         self.test_err_all = abs(onp.asarray(truth) - self.eqn.extended_sol)
         self.test_max_err = onp.max(self.test_err_all)
-        self.test_L2_err = onp.sqrt(onp.sum(self.test_err_all ** 2) / (self.eqn.N_test))
-        if print_option:
-            print(f'[Test error] Max error {self.test_max_err}')
-            print(f'[Test error] L2 error {self.test_L2_err}')
+        self.test_L2_err = _rms_over(self.test_err_all, self.eqn.N_test)
+        _say(print_option, 'test_max', v=self.test_max_err)
+        _say(print_option, 'test_l2', v=self.test_L2_err)
 
-    # ---- figures (cosmetic; need matplotlib only) ----------------------------------------------------------------------
-    def _scatter(self, with_data, title):
-        plt = _plt()
-        fig = plt.figure()
-        ax = fig.add_subplot(111)
-        e = self.eqn
-        series = [(e.X_domain, 'Interior nodes'), (e.X_boundary, 'Boundary nodes')]
-        if with_data:
-            series.append((e.X_domain[:e.N_data], 'Data nodes'))
-        for X, label in series:
-            ax.scatter(X[:, 0], X[:, 1], marker=None if with_data else 'x', label=label).set_clip_on(False)
-        ax.legend(loc="upper right")
-        plt.title(title)
-
+    # ---- figures (cosmetic; need matplotlib only): src/_figures.py ---------------------------------------------------------
     def show_sample(self):
-        self._scatter(False, 'Collocation points')
+        from . import _figures
+        _figures.scatter_points(self.eqn, False, 'Collocation points')
 
     def show_sample_IP(self):
-        self._scatter(True, 'Collocation and data points')
+        from . import _figures
+        _figures.scatter_points(self.eqn, True, 'Collocation and data points')
 
     def show_loss_hist(self):
-        plt = _plt()
-        plt.figure()
-        plt.plot(onp.arange(self.eqn.max_iter + 1), self.eqn.loss_hist)
-        plt.yscale("log")
-        plt.title('Loss function history')
-        plt.xlabel('Gauss-Newton step')
+        from . import _figures
+        _figures.loss_history(self.eqn)
 
     def contour_of_test_err(self, XX, YY):
-        plt = _plt()
-        fig = plt.figure()
-        ax = fig.add_subplot(111)
-        cs = ax.contourf(XX, YY, self.test_err_all.reshape(XX.shape), 50, cmap=plt.cm.coolwarm)
-        self.XX = XX
-        self.YY = YY
-        plt.xlabel('x_1')
-        plt.ylabel('x_2')
-        plt.title('Contour of errors')
-        fig.colorbar(cs)
-        plt.show()
+        from . import _figures
+        self.XX, self.YY = XX, YY
+        _figures.error_contour(XX, YY, self.test_err_all)
