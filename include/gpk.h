@@ -155,7 +155,8 @@ int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable);
 /* ---- micro-benchmarks used to fix the roofline denominators ------------------------------------------------ */
 int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops);      /* v_mfma_f64_16x16x4_f64 issue rate */
 int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, double* host_gbps);
-int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_per_op);   /* 0 dep. v_fma_f64, 1 indep. v_fma_f64, 2 dep. ds_read, 3 indep. ds_read, 4 dep. mfma_f64 (shader cycles per op, one wave) */
+int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_per_op);
+int gpk_ubench_xcc_map(gpk_handle h, int nblocks, int mode, int* host_out);   /* XCD id (HW_REG_XCC_ID) each workgroup ran on; mode 1: odd workgroups linger */   /* 0 dep. v_fma_f64, 1 indep. v_fma_f64, 2 dep. ds_read, 3 indep. ds_read, 4 dep. mfma_f64 (shader cycles per op, one wave) */
 
 #ifdef __cplusplus
 }

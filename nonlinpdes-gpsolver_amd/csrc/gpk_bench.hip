@@ -84,6 +84,16 @@ __global__ __launch_bounds__(64) void lat_probe_kernel(int mode, double* out, co
     const double s = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
     if (threadIdx.x == 0) { out[0] = (double)(t1 - t0) / N; out[1] = s; }
 }
+
+// which XCD does workgroup b land on?  (HW_REG_XCC_ID, bits 3:0)  mode 1: odd workgroups spin ~20 us, even ones exit at once
+__global__ __launch_bounds__(256) void xcc_probe_kernel(int* out, int mode) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc;
+    if (mode == 1 && (blockIdx.x & 1)) {
+        const long t0 = clock64();
+        while (clock64() - t0 < 40000) {}
+    }
+}
 }  // namespace
 
 extern "C" int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops) {
@@ -127,5 +137,17 @@ extern "C" int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_pe
     GPK_HIP(h, hipMemcpyAsync(host_cycles_per_op, h->d_scalars + 8, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
     if (gbuf) GPK_HIP(h, hipFree(gbuf));
+    return 0;
+}
+
+extern "C" int gpk_ubench_xcc_map(gpk_handle h, int nblocks, int mode, int* host_out) {
+    if (!h || !host_out || nblocks <= 0) return GPK_ERR_ARG;
+    int* d = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&d, nblocks * sizeof(int)));
+    xcc_probe_kernel<<<nblocks, 256, 0, h->stream>>>(d, mode);
+    GPK_LAUNCH_CHECK(h);
+    GPK_HIP(h, hipMemcpyAsync(host_out, d, nblocks * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    GPK_HIP(h, hipFree(d));
     return 0;
 }

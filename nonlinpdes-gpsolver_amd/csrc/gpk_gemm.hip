@@ -18,7 +18,9 @@
 //     m-contiguous operand : [k][BM+16]    (consecutive k rows offset by 128 bytes mod 256)
 //   MFMA operand map (cdna_hip_programming.md:247-251): A lane l = A[l&15][k=l>>4], B lane l = B[k=l>>4][l&15],
 //   C/D lane l reg r = C[(l>>4)+4r][l&15].
-// Workgroup -> tile map is XCD-aware: hardware places block b on XCD b%8, so logical tile ids are handed out in
+// Workgroup -> tile map is XCD-aware: workgroups go round-robin over the 8 XCDs (block b on XCD (b + offset) % 8, the
+// offset carried over from the previous launch: tools/xcc_probe.py reads HW_REG_XCC_ID), so blocks with equal b % 8 share
+// an L2 and logical tile ids are handed out in
 // 8 contiguous chunks (one per XCD L2), ordered in groups of 8 tile rows so that a chunk re-uses its A/B panels.
 #include "gpk_common.h"
 

@@ -69,6 +69,7 @@ PROTOTYPES = {
     'gpk_ubench_mfma_f64': (_i, [_vp, _i, _pd]),
     'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
     'gpk_ubench_latency': (_i, [_vp, _i, _pd]),
+    'gpk_ubench_xcc_map': (_i, [_vp, _i, _i, _pi]),
 }
 
 _lib = None
