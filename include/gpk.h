@@ -157,6 +157,10 @@ int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops);      /* v
 int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, double* host_gbps);
 int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_per_op);
 int gpk_ubench_xcc_map(gpk_handle h, int nblocks, int mode, int* host_out);   /* XCD id (HW_REG_XCC_ID) each workgroup ran on; mode 1: odd workgroups linger */   /* 0 dep. v_fma_f64, 1 indep. v_fma_f64, 2 dep. ds_read, 3 indep. ds_read, 4 dep. mfma_f64 (shader cycles per op, one wave) */
+/* development probe (tools/overlap_probe.py): C2 <- S^T S on a low-priority side stream while potrf(copy of H) runs on the
+ * handle's stream; host_ms3 = {potrf alone, syrk alone, both concurrently}.  Round-1 finding: no overlap (5.5 vs 2.9 + 2.5 ms). */
+int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,
+                            double* host_ms3);
 
 #ifdef __cplusplus
 }

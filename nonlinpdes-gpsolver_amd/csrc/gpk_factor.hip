@@ -1176,3 +1176,43 @@ extern "C" int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* 
     GPK_TRY(gpk_trsm(h, 0, L, n, ldl, B, nrhs, ldb));
     return gpk_trsm(h, 1, L, n, ldl, B, nrhs, ldb);
 }
+
+// development probe: does a big GEMM on a low-priority side stream hide behind the latency-bound Cholesky panel chain?
+// Runs  C2 <- S^T S  (n x n, k rows) on a side stream while  potrf(H)  runs on the handle's stream; returns the three
+// times in ms: potrf alone, syrk alone, both concurrently (wall).
+extern "C" int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,
+                                       double* host_ms3) {
+    if (!h || !H || !S || !C2 || !host_ms3) return GPK_ERR_ARG;
+    hipStream_t side = nullptr, main_s = h->stream;
+    int lo = 0, hi = 0;
+    GPK_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    GPK_HIP(h, hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
+    hipEvent_t e0, e1, ef;
+    GPK_HIP(h, hipEventCreate(&e0)); GPK_HIP(h, hipEventCreate(&e1)); GPK_HIP(h, hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+    double* Hc = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&Hc, (size_t)n * ldh * sizeof(double)));
+    float ms = 0.f;
+    for (int mode = 0; mode < 3; ++mode) {
+        GPK_HIP(h, hipMemcpyAsync(Hc, H, (size_t)n * ldh * sizeof(double), hipMemcpyDeviceToDevice, main_s));
+        GPK_HIP(h, hipStreamSynchronize(main_s));
+        GPK_HIP(h, hipEventRecord(e0, main_s));
+        if (mode == 1 || mode == 2) {
+            GPK_HIP(h, hipStreamWaitEvent(side, e0, 0));
+            h->stream = side;
+            int rc = gpk_i_gemm(h, true, false, n, n, k, 1.0, S, lds, S, lds, 0.0, C2, ldc, true);
+            h->stream = main_s;
+            if (rc) return rc;
+            GPK_HIP(h, hipEventRecord(ef, side));
+        }
+        if (mode == 0 || mode == 2) GPK_TRY(gpk_i_potrf(h, Hc, n, ldh, 0));
+        if (mode == 1 || mode == 2) GPK_HIP(h, hipStreamWaitEvent(main_s, ef, 0));
+        GPK_HIP(h, hipEventRecord(e1, main_s));
+        GPK_HIP(h, hipEventSynchronize(e1));
+        GPK_HIP(h, hipEventElapsedTime(&ms, e0, e1));
+        host_ms3[mode] = ms;
+    }
+    GPK_HIP(h, hipFree(Hc));
+    GPK_HIP(h, hipStreamDestroy(side));
+    GPK_HIP(h, hipEventDestroy(e0)); GPK_HIP(h, hipEventDestroy(e1)); GPK_HIP(h, hipEventDestroy(ef));
+    return 0;
+}

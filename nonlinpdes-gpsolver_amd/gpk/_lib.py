@@ -70,6 +70,7 @@ PROTOTYPES = {
     'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
     'gpk_ubench_latency': (_i, [_vp, _i, _pd]),
     'gpk_ubench_xcc_map': (_i, [_vp, _i, _i, _pi]),
+    'gpk_debug_overlap_probe': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _pd]),
 }
 
 _lib = None
