@@ -90,7 +90,13 @@ __device__ __forceinline__ void potf2_stage(const double* __restrict__ A, long l
 // vector; after the barrier every thread subtracts l[r] * l[c] from the columns c > j it owns.  The chain per column
 // is pivot broadcast -> rsqrt -> LDS round trip -> one FMA; the previous version (16-column panels factored redundantly
 // by every wave with 2 x (15 - j) lane broadcasts per column, then a blocked update) spent ~680 cycles per column.
-__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 4 x NB doubles, 16-byte aligned */, int n) {
+// TALL: the workgroup's own 64 rows BELOW the diagonal block ride along as extra rows of the right-looking loop (row r of
+// that block lives in xr[], same column ownership): scaling a column and subtracting the rank-2 terms is exactly the
+// column-oriented substitution X = B L^{-T}, so the row solve needs no pass of its own.  Finished columns of the extra
+// rows are written straight to memory (Xg: row block base, ldx, xrows valid rows).
+template <bool TALL>
+__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 8 x NB doubles, 16-byte aligned */, int n,
+                                          double* __restrict__ Xg = nullptr, long ldx = 0, int xrows = 0) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int r = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -99,11 +105,19 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
     // (Fully unrolled, the 64 columns were 31 KB of straight-line code executed once per launch; rolled it is 8 KB.  The
     // speed is the same, ~525 cycles per column = two rsqrt chains (~370 per pair) + LDS exchange and barrier (~250) +
     // the rank-2 update of up to 16 register columns (~310): measured, tools/stamp_probe.py with GPK_DEBUG_SET=5=0.)
-    double a[16];
+    double a[16], xr[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         a[2 * i] = As[r * XS + 8 * i + 2 * w];
         a[2 * i + 1] = As[r * XS + 8 * i + 2 * w + 1];
+    }
+    if (TALL) {
+        const double* __restrict__ xrow = Xg + (long)min(r, xrows - 1) * ldx;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xr[2 * i] = xrow[min(8 * i + 2 * w, n - 1)];
+            xr[2 * i + 1] = xrow[min(8 * i + 2 * w + 1, n - 1)];
+        }
     }
 #pragma unroll 1
     for (int o = 0; o < 8; ++o) {
@@ -111,20 +125,25 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
         if (jbase >= n) break;
         // Two columns per barrier: columns j, j+1 belong to the same wave (q), which finishes the first, applies it to the
         // second in registers (one lane broadcast), finishes the second and publishes both; everybody then subtracts both
-        // rank-1 terms at once.  Lc holds 2 (parity of the pair) x 2 (column of the pair) vectors of NB doubles.
+        // rank-1 terms at once.  Lc holds 2 (parity of the pair) x 4 vectors of NB doubles (two columns of the diagonal
+        // block's rows, two of the extra rows).
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int j = jbase + 2 * q;
             if (j < n) {
-                double* __restrict__ lc0 = Lc + (q & 1) * 2 * NB;
+                double* __restrict__ lc0 = Lc + (q & 1) * 4 * NB;
                 double* __restrict__ lc1 = lc0 + NB;
+                double* __restrict__ lx0 = lc0 + 2 * NB;
+                double* __restrict__ lx1 = lc0 + 3 * NB;
                 if (w == q) {
-                    double v[2] = {0.0, 0.0};
+                    double v[2] = {0.0, 0.0}, vx[2] = {0.0, 0.0};
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         if (t == 1) {
                             if (j + 1 >= n) break;
-                            a[1] = fma(-v[0], bcast_lane(v[0], j + 1), a[1]);   // times L[j+1][j]
+                            const double l10 = bcast_lane(v[0], j + 1);      // L[j+1][j]
+                            a[1] = fma(-v[0], l10, a[1]);
+                            if (TALL) xr[1] = fma(-vx[0], l10, xr[1]);
                         }
                         const double d = bcast_lane(a[t], j + t);        // pivot lives in lane j + t
                         // 1/sqrt(d), sqrt(d) by coupled Newton iterations from v_rsq_f64: g -> sqrt(d), hh -> 1/(2 sqrt(d))
@@ -137,12 +156,15 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
                         const double sq = fma(fma(-g, g, d), hh, g);     // one more correction for the diagonal entry
                         v[t] = (r == j + t) ? sq : a[t] * (hh + hh);     // LAPACK dpotf2 also scales by the reciprocal
                         a[t] = v[t];
+                        if (TALL) { vx[t] = xr[t] * (hh + hh); xr[t] = vx[t]; }
                     }
                     lc0[r] = v[0];
                     lc1[r] = v[1];
+                    if (TALL) { lx0[r] = vx[0]; lx1[r] = vx[1]; }
                 }
                 __syncthreads();
                 const double ml0 = lc0[r], ml1 = lc1[r];
+                const double mx0 = TALL ? lx0[r] : 0.0, mx1 = TALL ? lx1[r] : 0.0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (k < 8 - o) {                                     // (uniform) groups that still exist
@@ -155,6 +177,12 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
                         const bool take = (k > 0) || (w > q);
                         a[2 * k] = take ? u0 : a[2 * k];
                         a[2 * k + 1] = take ? u1 : a[2 * k + 1];
+                        if (TALL) {
+                            const double y0 = fma(-mx1, m1.x, fma(-mx0, m0.x, xr[2 * k]));
+                            const double y1 = fma(-mx1, m1.y, fma(-mx0, m0.y, xr[2 * k + 1]));
+                            xr[2 * k] = take ? y0 : xr[2 * k];
+                            xr[2 * k + 1] = take ? y1 : xr[2 * k + 1];
+                        }
                     }
                 }
             }
@@ -163,6 +191,15 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
         As[r * XS + jbase + 2 * w + 1] = a[1];
 #pragma unroll
         for (int k = 0; k < 14; ++k) a[k] = a[k + 2];
+        if (TALL) {
+            if (r < xrows) {
+                double* __restrict__ xrow = Xg + (long)r * ldx;
+                if (jbase + 2 * w < n) xrow[jbase + 2 * w] = xr[0];
+                if (jbase + 2 * w + 1 < n) xrow[jbase + 2 * w + 1] = xr[1];
+            }
+#pragma unroll
+            for (int k = 0; k < 14; ++k) xr[k] = xr[k + 2];
+        }
     }
     __syncthreads();
     // A non-positive (or NaN) pivot d gives rsqrt(d) = NaN or inf and a NaN on the diagonal, which then spreads: the
@@ -189,7 +226,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long
     potf2_stage(A, lda, n, As);
     __syncthreads();
     GPK_STAMP(1);
-    const int bad = potf2_tile(As, Ps, n);
+    const int bad = potf2_tile<false>(As, Ps, n);
     GPK_STAMP(2);
     potf2_store(A, lda, n, As);
     if (bad && bad <= n && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
@@ -332,7 +369,8 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
 // ---- Cholesky panel step, fused: factor the <=64-wide diagonal block AND solve the rows below against it ----------
 // Workgroup 0 factors A_jj and writes it back; every other workgroup owns 64 rows below, factors its own copy of A_jj
 // in LDS (redundant, but off nobody's critical path: the alternative is a second launch that first waits for the
-// factor to travel through memory) and solves X L_jj^T = A_rj by substitution.  One launch instead of two per panel.
+// factor to travel through memory) with its 64 rows riding along as extra rows of the right-looking loop (potf2_tile<true>):
+// the scaled and updated extra rows ARE X = A_rj L_jj^{-T}.  One launch instead of two per panel, 41 KB of LDS.
 // A_jj is overwritten in place, so workgroup 0 may only store once every other workgroup has READ the unfactored block
 // -- including those the hardware dispatches late when the grid exceeds what is resident (n > ~16000).  Each workgroup
 // takes a ticket on a global counter after its loads have landed; workgroup 0 waits for the running total `target`
@@ -341,14 +379,10 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
                                                           int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
     __shared__ double As[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ps[NB * RB];
-    __shared__ TrsmShared sh;
-    double tx[RB];                                                   // this workgroup's rows: fetched before the factorisation
-    if (blockIdx.x > 0) trsm_base_fetch<true>(A + (long)nb * lda, lda, nb, below, (int)blockIdx.x - 1, tx);
     potf2_stage(A, lda, nb, As);
     __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
-    if (blockIdx.x > 0 && threadIdx.x == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int bad = potf2_tile(As, Ps, nb);
     if (blockIdx.x == 0) {
+        const int bad = potf2_tile<false>(As, Ps, nb);
         if (threadIdx.x == 0) {
             int it = 0;                                              // (int) difference: robust to wrap-around of the counter
             while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
@@ -360,7 +394,9 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
         potf2_store(A, lda, nb, As);
         if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     } else {
-        trsm_base_body<false, true>(sh, As, XS, nb, A + (long)nb * lda, lda, below, (int)blockIdx.x - 1, 0, &tx);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int c0 = ((int)blockIdx.x - 1) * NB;                   // my 64 rows below the diagonal block
+        potf2_tile<true>(As, Ps, nb, A + (long)(nb + c0) * lda, lda, min(NB, below - c0));
     }
 }
 
@@ -460,7 +496,7 @@ __global__ __launch_bounds__(256) void potrf_ob_kernel(double* __restrict__ A, l
             if (!staged) potf2_stage(Tjj, lda, nbj, sh.u.f.As);      // (only workgroup 0: nobody touched its tile)
             __syncthreads();
             OB_STAMP(5);
-            const int bad = potf2_tile(sh.u.f.As, sh.u.f.Ps, nbj);
+            const int bad = potf2_tile<false>(sh.u.f.As, sh.u.f.Ps, nbj);
             OB_STAMP(6);
             potf2_store<true>(Tjj, lda, nbj, sh.u.f.As);
             if (bad && bad <= nbj && tid == 0) atomicCAS(info, 0, pivot_base + NB * j + bad);
