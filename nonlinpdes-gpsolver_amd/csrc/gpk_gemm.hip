@@ -100,6 +100,7 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 }
 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
+int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
 int g_supertile = 0;                                                 // gpk_debug_set key 6: 1 = supertile schedule for the leading-zero SYRK (below)
 
@@ -438,10 +439,11 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
     }
     dim3 grid(nblocks), block(256);
-    if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, 0, h->stream>>>(g);
-    else if (!ta && tb) gemm_f64_kernel<BM, BN, WM, WN, false, true><<<grid, block, 0, h->stream>>>(g);
-    else if (ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, true, false><<<grid, block, 0, h->stream>>>(g);
-    else gemm_f64_kernel<BM, BN, WM, WN, true, true><<<grid, block, 0, h->stream>>>(g);
+    const size_t dyn = (size_t)g_gemm_extra_lds;
+    if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, dyn, h->stream>>>(g);
+    else if (!ta && tb) gemm_f64_kernel<BM, BN, WM, WN, false, true><<<grid, block, dyn, h->stream>>>(g);
+    else if (ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, true, false><<<grid, block, dyn, h->stream>>>(g);
+    else gemm_f64_kernel<BM, BN, WM, WN, true, true><<<grid, block, dyn, h->stream>>>(g);
     GPK_LAUNCH_CHECK(h);
     return 0;
 }
@@ -476,6 +478,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 5) return gpk_debug_set_fused_panel(value);
     if (key == 7) return gpk_debug_set_persistent_ob(value);
     if (key == 8) { g_k64_small = value; return 0; }
+    if (key == 9) { g_gemm_extra_lds = value; return 0; }
     if (key == 6) { g_supertile = value; return 0; }
     return GPK_ERR_ARG;
 }
