@@ -94,9 +94,21 @@ __device__ __forceinline__ void potf2_stage(const double* __restrict__ A, long l
 // that block lives in xr[], same column ownership): scaling a column and subtracting the rank-2 terms is exactly the
 // column-oriented substitution X = B L^{-T}, so the row solve needs no pass of its own.  Finished columns of the extra
 // rows are written straight to memory (Xg: row block base, ldx, xrows valid rows).
+// the extra rows' entries this thread owns: columns {8i + 2w, 8i + 2w + 1}, i = 0..7, of row min(r, xrows-1)
+__device__ __forceinline__ void potf2_fetch_extra(const double* __restrict__ Xg, long ldx, int xrows, int n, double (&xr)[16]) {
+    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const double* __restrict__ xrow = Xg + (long)min(r, xrows - 1) * ldx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xr[2 * i] = xrow[min(8 * i + 2 * w, n - 1)];
+        xr[2 * i + 1] = xrow[min(8 * i + 2 * w + 1, n - 1)];
+    }
+}
+
 template <bool TALL>
 __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 8 x NB doubles, 16-byte aligned */, int n,
-                                          double* __restrict__ Xg = nullptr, long ldx = 0, int xrows = 0) {
+                                          double* __restrict__ Xg = nullptr, long ldx = 0, int xrows = 0,
+                                          const double (*xpre)[16] = nullptr) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     const int r = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,12 +124,8 @@ __device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __res
         a[2 * i + 1] = As[r * XS + 8 * i + 2 * w + 1];
     }
     if (TALL) {
-        const double* __restrict__ xrow = Xg + (long)min(r, xrows - 1) * ldx;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            xr[2 * i] = xrow[min(8 * i + 2 * w, n - 1)];
-            xr[2 * i + 1] = xrow[min(8 * i + 2 * w + 1, n - 1)];
-        }
+        for (int i = 0; i < 16; ++i) xr[i] = (*xpre)[i];             // fetched by the caller together with the diagonal block
     }
 #pragma unroll 1
     for (int o = 0; o < 8; ++o) {
@@ -379,6 +387,9 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
                                                           int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
     __shared__ double As[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ps[NB * RB];
+    const int c0 = ((int)blockIdx.x - 1) * NB;                       // blocks > 0: my 64 rows below the diagonal block
+    double xr[16];
+    if (blockIdx.x > 0) potf2_fetch_extra(A + (long)(nb + c0) * lda, lda, min(NB, below - c0), nb, xr);   // same round trip as A_jj
     potf2_stage(A, lda, nb, As);
     __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
     if (blockIdx.x == 0) {
@@ -395,8 +406,7 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
         if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     } else {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int c0 = ((int)blockIdx.x - 1) * NB;                   // my 64 rows below the diagonal block
-        potf2_tile<true>(As, Ps, nb, A + (long)(nb + c0) * lda, lda, min(NB, below - c0));
+        potf2_tile<true>(As, Ps, nb, A + (long)(nb + c0) * lda, lda, min(NB, below - c0), &xr);
     }
 }
 
