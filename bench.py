@@ -365,10 +365,14 @@ def main():
         from gpk.sharded import Comm
         out = run_single(args, workload, Comm() if world > 1 else None)
         if args.workload == 'auto' and not args.no_sharded_config:
-            sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
-            if out is not None and sh is not None:
-                out['sharded_config'] = {k: sh[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling',
-                                                             'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}
+            try:                                                  # the value above must survive a failure of the secondary run
+                sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
+                if out is not None and sh is not None:
+                    out['sharded_config'] = {k: sh[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling',
+                                                                 'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}
+            except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
+                if out is not None:
+                    out['sharded_config'] = {'error': f'{type(e).__name__}: {e}'}
     if use_pg:
         import torch.distributed as dist
         dist.barrier()
