@@ -38,10 +38,17 @@ class Comm:
             dist.broadcast(t, src=src, group=self.group)
 
     def all_gather(self, outs, t):
-        if self.world > 1:
-            dist.all_gather(outs, t, group=self.group)
-        else:
+        if self.world == 1:
             outs[0].copy_(t)
+        elif t.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # gloo has no all_gather for device tensors (it is only used for tests: several ranks sharing ONE GPU);
+            # emulate it with one broadcast per rank
+            for r in range(self.world):
+                if r == self.rank:
+                    outs[r].copy_(t)
+                dist.broadcast(outs[r], src=r, group=self.group)
+        else:
+            dist.all_gather(outs, t, group=self.group)
 
     def max_int(self, v, device):
         if self.world == 1:
