@@ -89,6 +89,11 @@ int gpk_symmetrize_lower(gpk_handle h, double* A, int n, int lda);   /* copy low
 /* jnp.linalg.solve(self.L, .) with the triangular factor (src/PDEs.py:86,97,143,161,288,306,429,450;
  * src/InverseProblems.py:118-119,145-146): B <- L^{-1} B (trans=0) or L^{-T} B (trans=1); B is n x nrhs. */
 int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+/* Tall block column A (nrows x ncols, nrows >= ncols <= 512 recommended): the top ncols x ncols block is replaced by its
+ * Cholesky factor L (lower) and the rows below by A[ncols:, :] L^{-T} -- one panel step of the blocked factorisation
+ * (jnp.linalg.cholesky, src/PDEs.py:77), the owner's share of a step of the panel-sharded multi-GPU factorisation.
+ * host_info as gpk_potrf (may be NULL: no host synchronisation then). */
+int gpk_potrf_panel(gpk_handle h, double* A, int nrows, int ncols, int lda, int* host_info);
 /* X <- X L^{-T} (X is m x n): the panel solve of the blocked Cholesky; exported for the multi-GPU panel-sharded
  * factorisation, whose per-panel schedule lives in the host layer (gpk/sharded.py). */
 int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);

@@ -1086,45 +1086,55 @@ int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X
 //   inside a panel, steps of NB = 64 columns, three launches each, every one covering ALL rows of the panel:
 //     potf2 (diagonal block)  ->  substitution of the rows below  ->  rank-64 update of the panel's remaining columns.
 // (A plain recursion needs ~15 launches per 64 columns, most of them a single wave.)
+// Factor a tall block column: D = A[0:ob, 0:ob] is replaced by its Cholesky factor and the rows below by A[ob:, 0:ob] D^{-T}
+// (64-column panel kernel + rank-64 update of the remaining columns, for all nrows rows).  The building block of both
+// the single-GPU factorisation below and the panel-sharded multi-GPU one (gpk/sharded.py, the owner's share of a step).
+int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base) {
+    if (ob <= 0 || nrows < ob) return 0;
+    if (g_persistent_ob) {
+        if (++h->ob_epoch == 0x7fffffff) {
+            GPK_HIP(h, hipMemsetAsync(h->d_obflags, 0, 64 * sizeof(int), h->stream));
+            h->ob_epoch = 1;
+        }
+        potrf_ob_kernel<<<gpk_ceil_div(nrows, NB), 256, 0, h->stream>>>(A, lda, nrows, ob, h->d_obflags, h->ob_epoch, h->d_info, pivot_base, g_dbg);
+        GPK_LAUNCH_CHECK(h);
+        return 0;
+    }
+    for (int j0 = 0; j0 < ob; j0 += NB) {
+        const int nb = (ob - j0 < NB) ? ob - j0 : NB;
+        double* Ajj = A + (long)j0 * lda + j0;
+        const int below = nrows - (j0 + nb);
+        if (g_fused_panel) {
+            const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
+            h->panel_loaded += (unsigned)nrb;
+            potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), h->panel_loaded, g_dbg);
+        } else {
+            potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
+            if (below > 0)
+                trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, g_dbg);
+        }
+        if (below > 0) {
+            double* Abj = A + (long)(j0 + nb) * lda + j0;
+            const int pc = ob - (j0 + nb);                           // remaining columns of this block column
+            if (pc > 0) {
+                // A[j0+nb:, j0+nb : ob] -= L[j0+nb:, j] * L[j0+nb : ob, j]^T   (rows above the diagonal of that block are
+                // computed too; they are never read)
+                GPK_TRY(gpk_i_gemm(h, false, true, below, pc, nb, -1.0, Abj, lda, Abj, lda, 1.0,
+                                   A + (long)(j0 + nb) * lda + (j0 + nb), lda, false));
+            }
+        }
+    }
+    GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     if (n <= 0) return 0;
     constexpr int OB = 512;
     for (int k0 = 0; k0 < n; k0 += OB) {
         const int ob = (n - k0 < OB) ? n - k0 : OB;
-        if (g_persistent_ob) {
-            if (++h->ob_epoch == 0x7fffffff) {
-                GPK_HIP(h, hipMemsetAsync(h->d_obflags, 0, 64 * sizeof(int), h->stream));
-                h->ob_epoch = 1;
-            }
-            potrf_ob_kernel<<<gpk_ceil_div(n - k0, NB), 256, 0, h->stream>>>(A + (long)k0 * lda + k0, lda, n - k0, ob, h->d_obflags,
-                                                                              h->ob_epoch, h->d_info, pivot_base + k0, g_dbg);
-        } else
-        for (int j0 = k0; j0 < k0 + ob; j0 += NB) {
-            const int nb = (k0 + ob - j0 < NB) ? k0 + ob - j0 : NB;
-            double* Ajj = A + (long)j0 * lda + j0;
-            const int below = n - (j0 + nb);
-            if (g_fused_panel) {
-                const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
-                h->panel_loaded += (unsigned)nrb;
-                potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                    (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), h->panel_loaded, g_dbg);
-            } else {
-                potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
-                if (below > 0)
-                    trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, g_dbg);
-            }
-            if (below > 0) {
-                double* Abj = A + (long)(j0 + nb) * lda + j0;
-                const int pc = k0 + ob - (j0 + nb);                   // remaining columns of this outer panel
-                if (pc > 0) {
-                    // A[j0+nb:, j0+nb : k0+ob] -= L[j0+nb:, j] * L[j0+nb : k0+ob, j]^T   (rows above the diagonal
-                    // of that block are computed too; they are never read)
-                    GPK_TRY(gpk_i_gemm(h, false, true, below, pc, nb, -1.0, Abj, lda, Abj, lda, 1.0,
-                                       A + (long)(j0 + nb) * lda + (j0 + nb), lda, false));
-                }
-            }
-        }
-        GPK_LAUNCH_CHECK(h);
+        GPK_TRY(gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, ob, lda, pivot_base + k0));
         const int rest = n - (k0 + ob);
         if (rest > 0) {
             double* P = A + (long)(k0 + ob) * lda + k0;               // factored panel rows below the outer block
@@ -1194,6 +1204,17 @@ extern "C" int gpk_potrf(gpk_handle h, double* A, int n, int lda, int* host_info
     if (!h || !A || n < 0 || lda < n) return GPK_ERR_ARG;
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     GPK_TRY(gpk_i_potrf(h, A, n, lda, 0));
+    if (host_info) {
+        GPK_HIP(h, hipMemcpyAsync(host_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        GPK_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+extern "C" int gpk_potrf_panel(gpk_handle h, double* A, int nrows, int ncols, int lda, int* host_info) {
+    if (!h || !A || ncols < 0 || nrows < ncols || lda < ncols) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    GPK_TRY(gpk_i_potrf_panel(h, A, nrows, ncols, lda, 0));
     if (host_info) {
         GPK_HIP(h, hipMemcpyAsync(host_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         GPK_HIP(h, hipStreamSynchronize(h->stream));

@@ -49,6 +49,7 @@ PROTOTYPES = {
     'gpk_potrf': (_i, [_vp, _vp, _i, _i, _pi]),
     'gpk_tril': (_i, [_vp, _vp, _i, _i]),
     'gpk_symmetrize_lower': (_i, [_vp, _vp, _i, _i]),
+    'gpk_potrf_panel': (_i, [_vp, _vp, _i, _i, _i, _pi]),
     'gpk_trsm': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
     'gpk_trsm_lz': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i]),
     'gpk_gemm_lz': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i, _i]),

@@ -93,6 +93,12 @@ class GpuBlockOps:
         self.ctx._chk(self.lib.gpk_potrf(self.h, self._p(A, r0, r0), n, A.stride(0), C.byref(info)))
         return info.value
 
+    def potrf_panel(self, A, r0, n, nrows):
+        """A[r0:r0+nrows, r0:r0+n]: factor the diagonal block and solve the rows below against it (one fused panel step)"""
+        info = C.c_int()
+        self.ctx._chk(self.lib.gpk_potrf_panel(self.h, self._p(A, r0, r0), nrows, n, A.stride(0), C.byref(info)))
+        return info.value
+
     def trsm_right(self, A, r0, n, row0, m):
         """A[row0:row0+m, r0:r0+n] <- A[...] * L^{-T} with L = A[r0:r0+n, r0:r0+n]"""
         self.ctx._chk(self.lib.gpk_trsm_right_lt(self.h, self._p(A, r0, r0), n, A.stride(0), self._p(A, row0, r0), m, A.stride(0)))
@@ -161,11 +167,9 @@ class ShardedFactorSolve:
             owner = k % P
             panel = self._panel_buf(A, n - k0, kb)
             if rank == owner:
-                i = ops.potrf(A, k0, kb)
+                i = ops.potrf_panel(A, k0, kb, n - k0)             # diagonal block + the rows below, fused panel kernels
                 if i and not info:
                     info = k0 + i
-                if below:
-                    ops.trsm_right(A, k0, kb, k0 + kb, below)
                 if P > 1:
                     panel.copy_(A[k0:n, k0:k0 + kb])
             if P > 1:

@@ -20,6 +20,12 @@ class NumpyBlockOps:
         blk[np.tril_indices(n)] = L[np.tril_indices(n)]
         return 0
 
+    def potrf_panel(self, A, r0, n, nrows):
+        info = self.potrf(A, r0, n)
+        if nrows > n and info == 0:
+            self.trsm_right(A, r0, n, r0 + n, nrows - n)
+        return info
+
     def trsm_right(self, A, r0, n, row0, m):
         a = A.numpy()
         L = np.tril(a[r0:r0 + n, r0:r0 + n])
