@@ -16,8 +16,9 @@ values form the strong-scaling curve of BASELINE config 5; `--workload c5` makes
 A "step" is one Gauss-Newton step of the reference's GN_method (src/PDEs.py:117-127): Hessian_GN + grad_loss + linear
 solve + update + one loss evaluation, executed as TRSM (n_z+1 right-hand sides) + SYRK + Cholesky of H + triangular
 solve, all operands resident in HBM.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded inside the timed steps on the
-stream the kernels run on; `cpu_baseline` times the CPU oracle (reference operation sequence) on this box's host cores.
+Rank 0 prints ONE JSON line.  `roofline.achieved` is measured live with HIP events recorded inside the timed steps on
+the stream the kernels run on; `roofline.traffic` is read from the newest stored PMC pass under profiles/ and says so
+(`traffic_source`); `cpu_baseline` times the CPU oracle (reference operation sequence) on this box's host cores.
 """
 import argparse
 import ctypes as C
@@ -92,6 +93,67 @@ def syrk_executed_flops(N, nz, tile=64, bk=16):
     return total
 
 
+def stored_pmc_traffic():
+    """`roofline.traffic` cannot be measured inside this process (PMC counters need a rocprofv3 --pmc pass of their own,
+    tools/profile_round.sh): it is READ from the newest committed profiles/rNN_pmc_syrk.json and labelled as such."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_syrk.json')))
+    for path in reversed(files):
+        try:
+            v = json.load(open(path)).get('hbm_bytes_per_launch')
+        except Exception:
+            continue
+        if v is not None:
+            return v, (f'stored PMC pass profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same '
+                       f'kernel at this workload); not measured in this run')
+    return None, 'no stored PMC pass found'
+
+
+class AbortWatch:
+    """N > 1 ranks: a rank that fails in the middle of the secondary (sharded) run cannot tell peers that are blocked
+    inside a collective -- they would sit there until the RCCL timeout and the primary value would be lost.  Every rank
+    therefore polls a key of the rendezvous store from a daemon thread while that run is in flight; the failing rank sets
+    it, and on seeing it rank 0 prints the one JSON line (primary value + the error) and every rank leaves the process
+    without touching the process group again."""
+    KEY = 'gpk_bench_abort'
+
+    def __init__(self, rank, primary_out):
+        import threading
+        import torch.distributed as dist
+        self.rank, self.out = rank, primary_out
+        self.store = dist.distributed_c10d._get_default_store()
+        self.done = threading.Event()
+        self.thread = threading.Thread(target=self._poll, daemon=True)
+        self.thread.start()
+
+    def _finish(self, msg):
+        if self.rank == 0 and self.out is not None:
+            self.out['sharded_config'] = {'error': msg}
+            print(json.dumps(self.out), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+
+    def _poll(self):
+        while not self.done.wait(0.5):
+            try:
+                if self.store.check([self.KEY]):
+                    self._finish(self.store.get(self.KEY).decode(errors='replace'))
+            except Exception:                                     # store gone: the job is being torn down anyway
+                return
+
+    def fail(self, msg):
+        """called by the rank that caught the exception"""
+        try:
+            self.store.set(self.KEY, msg)
+        except Exception:
+            pass
+        self._finish(msg)
+
+    def stop(self):
+        self.done.set()
+        self.thread.join(timeout=5)
+
+
 # ------------------------------------------------------------------------------------------------------ single GPU
 def run_single(args, workload, comm=None):
     """One independent solve on this rank's GPU.  With `comm` (N > 1 ranks): the timed region is bracketed by barriers and
@@ -163,13 +225,7 @@ def run_single(args, workload, comm=None):
     syrk_flops = syrk_executed_flops(N, nz)                      # what the launch executes (leading zeros skipped)
     syrk_dense = float(N) * (nz + 1) ** 2                        # dense symmetric count, SURVEY 8d ("SYRK N n_z^2")
     achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_syrk.json')
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
+    traffic, traffic_source = stored_pmc_traffic()
     out = {
         'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
         'value': world * args.steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -191,7 +247,7 @@ def run_single(args, workload, comm=None):
         'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms},
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<TN, lower tiles> = SYRK Hb = S^T S',
                      'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
-                     'traffic': traffic, 'flops_per_launch': syrk_flops, 'dense_flops_per_launch': syrk_dense,
+                     'traffic': traffic, 'traffic_source': traffic_source, 'flops_per_launch': syrk_flops, 'dense_flops_per_launch': syrk_dense,
                      'dense_equivalent_tflops': syrk_dense / (syrk_ms * 1e-3) / 1e12, 'avg_launch_ms': syrk_ms,
                      'peak_source': 'datasheet fp64 matrix rate; v_mfma_f64_16x16x4_f64 issue-rate ubench on this chip ~74'},
         'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble_kernel<elliptic>', 'achieved': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
@@ -365,14 +421,20 @@ def main():
         from gpk.sharded import Comm
         out = run_single(args, workload, Comm() if world > 1 else None)
         if args.workload == 'auto' and not args.no_sharded_config:
+            watch = AbortWatch(int(os.environ.get('RANK', '0')), out) if use_pg else None
             try:                                                  # the value above must survive a failure of the secondary run
                 sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
                 if out is not None and sh is not None:
                     out['sharded_config'] = {k: sh[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling',
                                                                  'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
+                msg = f'{type(e).__name__}: {e}'
+                if watch is not None:
+                    watch.fail(f"rank {os.environ.get('RANK', '0')}: {msg}")      # does not return (peers may be blocked in a collective)
                 if out is not None:
-                    out['sharded_config'] = {'error': f'{type(e).__name__}: {e}'}
+                    out['sharded_config'] = {'error': msg}
+            if watch is not None:
+                watch.stop()
     if use_pg:
         import torch.distributed as dist
         dist.barrier()

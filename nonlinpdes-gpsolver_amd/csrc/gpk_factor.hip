@@ -58,6 +58,11 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane /* wave-unif
 
 // Cross-workgroup data of the persistent kernels travels with agent-scope relaxed atomics (sc1 on gfx950: stores write
 // through to memory, loads bypass the XCD-private L2), so a hand-off needs no L2 write-back / invalidate fence.
+// Publishing side of such a hand-off: the flag store must not overtake the payload.  A workgroup-scope release fence
+// emits NO wait on gfx950 (the payload and the flag may travel to different L2 channels), and the compiler may drop the
+// s_waitcnt of an agent-scope fence when it believes the scoreboard is empty (MI355X_MICROARCH.md, "Compiler hazard"),
+// so the wait is spelled out: every wave that stored payload executes it before the barrier / the flag store.
+__device__ __forceinline__ void gpk_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <bool COH> __device__ __forceinline__ double ld_g(const double* p) {
     if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
@@ -394,14 +399,20 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
     if (blockIdx.x == 0) {
         const int bad = potf2_tile<false>(As, Ps, nb);
+        __shared__ int expired;
         if (threadIdx.x == 0) {
-            int it = 0;                                              // (int) difference: robust to wrap-around of the counter
+            int it = 0, ex = 0;                                      // (int) difference: robust to wrap-around of the counter
             while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++it > (1 << 24)) break;                         // cannot happen: the other workgroups never wait
-            }
+                if (++it > (1 << 24)) { ex = 1; break; }             // the other workgroups never wait, so this means a lost
+            }                                                        // launch or a desynchronised counter: fail loudly
+            expired = ex;
         }
         __syncthreads();
+        if (expired) {                                               // do NOT overwrite a block somebody may still have to read
+            if (threadIdx.x == 0) atomicCAS(info, 0, -1);
+            return;
+        }
         potf2_store(A, lda, nb, As);
         if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
     } else {
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(256) void potrf_ob_kernel(double* __restrict__ A, l
             OB_STAMP(6);
             potf2_store<true>(Tjj, lda, nbj, sh.u.f.As);
             if (bad && bad <= nbj && tid == 0) atomicCAS(info, 0, pivot_base + NB * j + bad);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // = s_waitcnt: the write-through stores have landed
+            gpk_drain_stores();                                      // every storing wave waits for its own write-through stores
             __syncthreads();
             if (tid == 0) __hip_atomic_store(&flags[8 * j + j], ok ? epoch : -epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             OB_STAMP(7);
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(256) void potrf_ob_kernel(double* __restrict__ A, l
         OB_STAMP(2);
         trsm_base_body<false, true, true>(sh.u.t, Tjj, lda, nbj, Bj, lda, below, r - j - 1, dbg, &tx);   // X_r -> memory and t.Ys
         if (r < J) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            gpk_drain_stores();
             __syncthreads();
             if (tid == 0) __hip_atomic_store(&flags[8 * j + r], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(64) void trsv_diag_kernel(const double* __restrict_
 // x_w.  A workgroup only ever waits for workgroups with a smaller blockIdx, which the hardware dispatches first, so the
 // wait chain cannot deadlock; the spin is bounded anyway and poisons the result with NaN if it ever expires.
 // Visibility across the eight XCD-private L2s: x_w is stored with agent-scope atomic stores (write-through) and the
-// flag store follows once they have landed (s_waitcnt); readers poll the flag and read x_d with agent-scope atomic loads
+// flag store follows once they have been acknowledged (explicit s_waitcnt vmcnt(0), gpk_drain_stores); readers poll the flag and read x_d with agent-scope atomic loads
 // (cache-bypassing) -- no L2 write-back / invalidate fence on the chain.  The 64 x 64 coefficient tiles are single-use and prefetched one dependency ahead, independent of the flags.
 // Measured: 329 us for n = 4000 backward (5.2 us per link of the chain: release, flag visibility, poll, acquire, the
 // x_d loads, 64 substitution steps).  Tried and slower: the chain on a single XCD (tile stream on 32 CUs only, 698 us);
@@ -889,7 +900,7 @@ __global__ __launch_bounds__(256) void trsv_fused_kernel(const double* __restric
         }
         if (__builtin_amdgcn_readfirstlane((int)dead)) res = __builtin_nan("");
         if (r < nb) __hip_atomic_store(&x[r0 + r], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // = s_waitcnt: the write-through stores have landed
+        gpk_drain_stores();                                          // this wave's write-through stores have been acknowledged
         if (r == 0) __hip_atomic_store(&flags[bid], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1106,9 +1117,11 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
         const int below = nrows - (j0 + nb);
         if (g_fused_panel) {
             const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
-            h->panel_loaded += (unsigned)nrb;
+            const unsigned target = h->panel_loaded + (unsigned)nrb;
             potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), h->panel_loaded, g_dbg);
+                                                                (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+            GPK_LAUNCH_CHECK(h);                                     // a failed launch issues no tickets: count them only now
+            h->panel_loaded = target;
         } else {
             potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
             if (below > 0)

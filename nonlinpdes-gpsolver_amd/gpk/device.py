@@ -1,6 +1,7 @@
 """Thin object layer over the C ABI: a context (handle + stream), device arrays with a padded leading dimension,
 and the calls of include/gpk.h with numpy-friendly signatures."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -37,6 +38,7 @@ class DeviceArray:
         p = C.c_void_p()
         ctx._chk(ctx.lib.gpk_malloc(ctx.h, self.nbytes, C.byref(p)))
         self.ptr = p.value
+        ctx._live.add(self)
         if zero:
             self.zero()
 
@@ -69,9 +71,11 @@ class DeviceArray:
         return self.ptr + (row * self.ld + col) * 8
 
     def free(self):
-        if getattr(self, 'ptr', None):
-            self.ctx.lib.gpk_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        """Release the buffer.  Context.close() frees every array still alive, so after close() this is a no-op."""
+        ptr, self.ptr = getattr(self, 'ptr', None), None
+        if ptr and self.ctx.h:
+            self.ctx._live.discard(self)
+            self.ctx._chk(self.ctx.lib.gpk_free(self.ctx.h, ptr))
 
     def __del__(self):
         try:
@@ -136,6 +140,7 @@ class Context:
             raise GpkError(f'gpk_create(device={device}) failed with {rc}: no usable gfx950 device '
                            '(this library has no CPU fallback)')
         self.h = h
+        self._live = weakref.WeakSet()          # device arrays allocated through this context and not yet freed
 
     def _chk(self, rc):
         if rc < 0:
@@ -143,7 +148,10 @@ class Context:
         return rc
 
     def close(self):
+        """Free every device array still alive (their handles become inert), then destroy the handle."""
         if getattr(self, 'h', None):
+            for a in list(self._live):
+                a.free()
             self.lib.gpk_destroy(self.h)
             self.h = None
 
@@ -223,7 +231,14 @@ class Context:
         n = A.rows if n is None else n
         info = C.c_int()
         self._chk(self.lib.gpk_potrf(self.h, A.ptr, n, A.ld, C.byref(info)))
-        return info.value
+        return self._chk_info(info.value)
+
+    @staticmethod
+    def _chk_info(info):
+        """> 0 is LAPACK's info (first non-positive pivot); < 0 means a bounded device-side wait expired (lost launch)."""
+        if info < 0:
+            raise GpkError(f'libgpk: a device-side wait expired inside the factorisation (info = {info}); the result is invalid')
+        return info
 
     def tril(self, A, n=None):
         self._chk(self.lib.gpk_tril(self.h, A.ptr, A.rows if n is None else n, A.ld))
@@ -253,7 +268,7 @@ class Context:
         loss, info = C.c_double(), C.c_int()
         self._chk(self.lib.gpk_gn_step(self.h, C.byref(prob.struct), z.ptr, float(step_size), S.ptr, S.ld, H.ptr, H.ld,
                                        delta.ptr, C.byref(loss), C.byref(info)))
-        return loss.value, info.value
+        return loss.value, self._chk_info(info.value)
 
     def gn_loss(self, prob, z):
         _, _, _, work = prob.workspace()

@@ -91,13 +91,13 @@ class GpuBlockOps:
     def potrf(self, A, r0, n):
         info = C.c_int()
         self.ctx._chk(self.lib.gpk_potrf(self.h, self._p(A, r0, r0), n, A.stride(0), C.byref(info)))
-        return info.value
+        return self.ctx._chk_info(info.value)
 
     def potrf_panel(self, A, r0, n, nrows):
         """A[r0:r0+nrows, r0:r0+n]: factor the diagonal block and solve the rows below against it (one fused panel step)"""
         info = C.c_int()
         self.ctx._chk(self.lib.gpk_potrf_panel(self.h, self._p(A, r0, r0), nrows, n, A.stride(0), C.byref(info)))
-        return info.value
+        return self.ctx._chk_info(info.value)
 
     def trsm_right(self, A, r0, n, row0, m):
         """A[row0:row0+m, r0:r0+n] <- A[...] * L^{-T} with L = A[r0:r0+n, r0:r0+n]"""

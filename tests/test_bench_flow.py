@@ -54,3 +54,41 @@ def test_two_rank_flow_prints_one_line(tmp_path):
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
     assert abs(d['value'] - 2 * 4 / 1.5) < 1e-9                  # max over ranks of (0.5, 1.5)
     assert d['sharded_config']['n_gpus'] == 1 and 'roofline' in d['sharded_config']
+
+
+def test_two_rank_flow_survives_a_one_sided_failure(tmp_path):
+    """Rank 1 fails in the middle of the sharded run while rank 0 is blocked in a collective: rank 0 must still print the
+    primary value (with the error attached) and both ranks must leave promptly with exit code 0."""
+    script = tmp_path / 'drive.py'
+    script.write_text(textwrap.dedent(f'''
+        import os, sys, time
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'nonlinpdes-gpsolver_amd'))
+        import bench
+        def fake_single(args, workload, comm=None):
+            comm.barrier()
+            out = {{'metric': 'm', 'value': 42.0, 'n_gpus': comm.world, 'scaling': 'weak', 'steps': args.steps}}
+            return out if comm.rank == 0 else None
+        def fake_sharded(args, workload, steps=None, warmup=None):
+            import torch.distributed as dist
+            if dist.get_rank() == 1:
+                time.sleep(1.0)
+                raise RuntimeError('libgpk error -2: out of memory (simulated)')
+            dist.barrier()                                       # rank 0 waits for a peer that never arrives
+            return None
+        bench.run_single, bench.run_sharded = fake_single, fake_sharded
+        sys.argv = ['bench.py', '--gpus', '2', '--steps', '4', '--warmup', '1']
+        bench.main()
+    '''))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), GPK_BENCH_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    lines = [l for o in outs for l in o[0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['value'] == 42.0 and d['n_gpus'] == 2
+    assert 'out of memory (simulated)' in d['sharded_config']['error'] and 'rank 1' in d['sharded_config']['error']
