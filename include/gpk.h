@@ -109,6 +109,17 @@ int gpk_gemm(gpk_handle h, int ta, int tb, int m, int n, int k, double alpha, co
 int gpk_trsm_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead);
 int gpk_gemm_lz(gpk_handle h, int ta, int m, int n, int k, double alpha, const double* A, int lda,
                 const double* B, int ldb, double beta, double* C, int ldc, int lead);
+/* Companion of a Cholesky factor that is reused for many multi-right-hand-side forward solves (the factor of Theta in
+ * GN_method: jnp.linalg.solve(self.L, .) inside every Hessian_GN, src/PDEs.py:97,306,450; src/InverseProblems.py:145-146):
+ * Dinv (n x 256 doubles, leading dimension 256) receives the inverses of the 256 x 256 diagonal blocks of L, block k in rows
+ * [256k, 256k + n_k), computed by substitution.  gpk_trsm_dinv then solves L X = B with GEMMs only: X (n x nrhs, ld ldx, must
+ * not alias B) receives L^{-1} B, B is overwritten with intermediate values.  lead > 0: column c < lead of B is zero above row
+ * lead-1-c (as gpk_trsm_lz); the zero part of X left of that boundary is NOT written, so X must be zero there on entry
+ * (zero X once; solves of the same shape keep it valid).  Accuracy: DESIGN.md section 4 (measured 5e-14 relative on the
+ * Gauss-Newton iterates at nugget 1e-13). */
+int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv);
+int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int nrhs, int ldb,
+                  double* X, int ldx, int lead);
 /* C <- alpha*A^T A + beta*C, A is k x n row-major; lower triangle only unless full != 0
  * (the 2*ss^T ss of src/PDEs.py:307 and of every autodiff Hessian_GN). */
 int gpk_syrk(gpk_handle h, int n, int k, double alpha, const double* A, int lda, double beta, double* C, int ldc, int full);
@@ -124,10 +135,13 @@ typedef struct {
     const double* data_u;    /* (Ndata,) DARCY only */
     const double* L;  int ldl;     /* factor of Theta (DARCY: L_u) */
     const double* L2; int ldl2;    /* DARCY: L_a */
+    const double* Dinv;            /* optional (may be NULL): gpk_trtri_diag(L)  -- the S solve then runs as GEMMs only */
+    const double* Dinv2;           /* optional, DARCY: gpk_trtri_diag(L2) */
 } gpk_gn_problem;
 
 /* sizes: nz unknowns, rows of the stacked S = [L^{-1}A | L^{-1}F] buffer */
 int gpk_gn_dims(const gpk_gn_problem* host_prob, int* nz, int* s_rows);
+/* (With host_prob->Dinv set, S is scratch and the solved block lives in the handle's workspace.) */
 /* One Gauss-Newton step = Hessian_GN + grad_loss + linear solve + update (src/PDEs.py:117-119,322-325,472-475;
  * src/InverseProblems.py:164-166) and the loss of the INPUT iterate (src/PDEs.py:82-87 ...):
  *   S  = [L^{-1}A(z) | L^{-1}F(z)]                (s_rows x (nz+1), ld lds)

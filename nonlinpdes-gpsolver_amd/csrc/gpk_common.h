@@ -24,6 +24,10 @@ struct gpk_ctx {
     int* d_obflags = nullptr;       // 64 flags of the persistent outer-block Cholesky kernel (epoch-tagged)
     int ob_epoch = 0;
     unsigned panel_loaded = 0;      // running total of "diagonal block loaded" tickets issued to the Cholesky panel kernel (d_flags[GPK_MAX_TRSV_BLOCKS])
+    double* d_work = nullptr;       // scratch of the Gauss-Newton step: the out-of-place solution of the Dinv solve
+    size_t work_cap = 0;            // bytes
+    long work_sig[5] = {0, 0, 0, 0, 0};   // (rows, ld, nrhs, lead, system) of the last solve into d_work: its never-written
+                                    // zero region is still valid when the next solve has the same shape
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
@@ -55,13 +59,19 @@ int gpk_bad_arg(gpk_handle h, const char* what);
 // ---- internal (stream-ordered, no host sync) building blocks -------------------------------------------------
 // C <- alpha*op(A)*op(B) + beta*C.  lower_only: skip tiles strictly above the diagonal (square C).
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
-               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0);
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0, bool tri_a = false);
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 // forward solve exploiting leading zeros of the right-hand side columns (see gpk_factor.hip)
 int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead, int row0);
 // same, right-hand sides split into independent column groups that run on concurrent streams
 int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
+// explicit inverses of the 256 x 256 diagonal blocks of L (Dinv: n x 256, ld 256) and the all-GEMM forward solve built on
+// them: X <- L^{-1} B out of place, B is scratch afterwards (see gpk_factor.hip)
+int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv);
+int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int ldb,
+                         double* X, int ldx, int nrhs, int lead, int row0);
+int gpk_i_workspace(gpk_handle h, size_t bytes, double** out);                          // handle-owned scratch, grown on demand
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);
 int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x);   // x contiguous
 int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_out);    // d_out device scalar

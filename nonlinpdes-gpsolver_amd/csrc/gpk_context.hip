@@ -53,6 +53,7 @@ extern "C" int gpk_destroy(gpk_handle h) {
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_obflags) (void)hipFree(h->d_obflags);
     if (h->d_pts) (void)hipFree(h->d_pts);
+    if (h->d_work) (void)hipFree(h->d_work);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 3; ++i) {
@@ -189,5 +190,18 @@ int gpk_i_ensure_points(gpk_handle h, size_t doubles) {
     h->d_pts = nullptr; h->pts_cap = 0;
     GPK_HIP(h, hipMalloc((void**)&h->d_pts, doubles * sizeof(double)));
     h->pts_cap = doubles;
+    return 0;
+}
+
+int gpk_i_workspace(gpk_handle h, size_t bytes, double** out) {
+    if (h->work_cap < bytes) {
+        GPK_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->d_work) GPK_HIP(h, hipFree(h->d_work));
+        h->d_work = nullptr; h->work_cap = 0;
+        for (long& v : h->work_sig) v = 0;
+        GPK_HIP(h, hipMalloc((void**)&h->d_work, bytes));
+        h->work_cap = bytes;
+    }
+    *out = h->d_work;
     return 0;
 }

@@ -1033,6 +1033,61 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
     return 0;
 }
 
+// ---- multi-right-hand-side forward solve through explicit inverses of the diagonal blocks ---------------------------------
+// The factor L of Theta is fixed for the whole Gauss-Newton iteration while S = L^{-1}[A | F] is recomputed every step, and
+// in that solve the only work that is not a GEMM is the 256-row strip substitution: a latency chain (33 strips x 33 us =
+// 1.1 ms of the 4.3 ms TRSM phase at BASELINE config 2).  gpk_trtri_diag computes, ONCE per factor and by the same true
+// substitution (strip kernel on an identity right-hand side), the inverses of the 256 x 256 diagonal blocks; the strip solve
+// then is X_k = inv(L_kk) B_k, a GEMM with a lower-triangular operand (K loop cut at the diagonal per row tile), and the
+// whole TRSM runs on the matrix cores.  This is what MAGMA / rocBLAS do for trsm; it is only conditionally stable, so it was
+// checked on this problem class before being adopted: the residual of inv(L_kk) B_k is bounded by eps cond(L_kk) |B_k| instead
+// of eps |L_kk| |X_k|, which is the same size whenever X is large relative to B -- the case here (|L^{-1}A| ~ 1e8).  Measured
+// with the CPU oracle at nugget 1e-13 (cond(L) = 1.8e9, diagonal blocks up to 1.5e7): Gauss-Newton iterates differ from the
+// substitution path by 8e-14 (config 1) and 5e-14 (config 2) relative; 1024-wide blocks would give 3e-10, still far inside
+// the 1e-6 parity bound.  Only the diagonal BLOCKS are inverted; L itself never is.
+// Out of place: the leaf writes X_k = inv(L_kk) B_k into a second buffer (a GEMM cannot run in place over its K range), the
+// updates B_2 -= L_21 X_1 read X and modify B, so on return X holds the solution and B is scratch.
+__global__ void dinv_identity_kernel(double* __restrict__ D, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                    // one thread per entry of the n x DB array
+    if (i < n * SB) D[i] = ((i / SB) % SB == i % SB) ? 1.0 : 0.0;
+}
+
+int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv) {
+    if (n <= 0) return 0;
+    dinv_identity_kernel<<<gpk_ceil_div(n * SB, 256), 256, 0, h->stream>>>(Dinv, n);
+    GPK_LAUNCH_CHECK(h);
+    for (int k0 = 0; k0 < n; k0 += SB) {
+        const int nk = (n - k0 < SB) ? n - k0 : SB;
+        // (substitution keeps the zeros above the diagonal of the inverse exact: x_i = (0 - sum 0) / l_ii)
+        GPK_TRY(gpk_i_trsm_left(h, false, L + (long)k0 * ldl + k0, nk, ldl, Dinv + (long)k0 * SB, nk, SB));
+    }
+    return 0;
+}
+
+int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int ldb,
+                         double* X, int ldx, int nrhs, int lead, int row0) {
+    if (n <= 0 || nrhs <= 0) return 0;
+    int clo = lead - (row0 + n);                                     // (lead = 0: dense right-hand sides)
+    clo = clo > 0 ? (clo / NB) * NB : 0;
+    if (clo >= nrhs) return 0;
+    if (n <= SB) {
+        const int lz = lead - row0 - clo;
+        return gpk_i_gemm(h, false, false, n, nrhs - clo, n, 1.0, Dinv + (long)row0 * SB, SB, B + clo, ldb, 0.0, X + clo, ldx,
+                          false, lz > 0 ? lz : 0, true);
+    }
+    const int n1 = split(n, SB), n2 = n - n1;
+    const double* L21 = L + (long)n1 * ldl;
+    GPK_TRY(gpk_i_trsm_left_dinv(h, L, Dinv, n1, ldl, B, ldb, X, ldx, nrhs, lead, row0));
+    int c1 = lead - (row0 + n1);                                     // X[rows of part 1] is zero left of this column
+    c1 = c1 > 0 ? (c1 / NB) * NB : 0;
+    if (c1 < nrhs) {
+        const int lz = lead - row0 - c1;
+        GPK_TRY(gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, X + c1, ldx, 1.0, B + (long)n1 * ldb + c1, ldb,
+                           false, lz > 0 ? lz : 0));
+    }
+    return gpk_i_trsm_left_dinv(h, L21 + n1, Dinv, n2, ldl, B + (long)n1 * ldb, ldb, X + (long)n1 * ldx, ldx, nrhs, lead, row0 + n1);
+}
+
 // The 64-row diagonal solves of a multi-RHS TRSM keep only nrhs/64 waves busy and sit on the critical path between
 // the GEMM updates.  Column groups of the right-hand side are independent, so they are issued on separate streams:
 // while one group runs a (latency-bound) diagonal solve the other groups' GEMMs fill the chip.
@@ -1245,6 +1300,18 @@ extern "C" int gpk_trsm_lz(gpk_handle h, const double* L, int n, int ldl, double
     if (!h || !L || !B || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs) return GPK_ERR_ARG;
     if (lead <= 0) return gpk_i_trsm_left_mt(h, false, L, n, ldl, B, nrhs, ldb);
     return gpk_i_trsm_left_lz(h, L, n, ldl, B, nrhs, ldb, lead, 0);
+}
+
+extern "C" int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv) {
+    if (!h || !L || !Dinv || n < 0 || ldl < n) return GPK_ERR_ARG;
+    return gpk_i_trtri_diag(h, L, n, ldl, Dinv);
+}
+
+extern "C" int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int nrhs, int ldb,
+                             double* X, int ldx, int lead) {
+    if (!h || !L || !Dinv || !B || !X || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs || ldx < nrhs) return GPK_ERR_ARG;
+    if (B == X) return gpk_bad_arg(h, "trsm_dinv: X must not alias B");
+    return gpk_i_trsm_left_dinv(h, L, Dinv, n, ldl, B, ldb, X, ldx, nrhs, lead > 0 ? lead : 0, 0);
 }
 
 extern "C" int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {

@@ -41,6 +41,8 @@ struct GemmArgs {
     int lead;          // operand B (stored [k][n]) has column n zero for k < lead-1-n: the tile with columns [n0, n0+BN)
                        // gets no contribution from k < lead - (n0 + BN), so its K loop starts there.  (SYRK S^T S,
                        // lower tiles: the A tile's columns are further right, i.e. non-zero even earlier.)
+    int tri_a;         // operand A (TA = false, stored [m][k]) is lower triangular: row m has no entries at k > m, so the tile
+                       // with rows [m0, m0+BM) stops its K loop at m0+BM (the explicit inverses of diagonal blocks, gpk_trsm_dinv)
     int vecA, vecB;
     int ntm, ntn, ntiles;
     int nsuper;        // > 0: supertile schedule of the lower-triangular, leading-zero (SYRK) launch, see map_tile
@@ -194,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int nk = (g.K + BK - 1) / BK;
+    const int Kt = g.tri_a ? min(g.K, m0 + BM) : g.K;                 // lower-triangular A: nothing right of the tile's last row
+    const int nk = (Kt + BK - 1) / BK;
     int kt0 = 0;
     if (g.lead > 0) {                                                 // both operands are zero above this row (tm >= tn)
         // supertile schedule: every tile of a supertile starts where its right-most column block does (<= 12 slabs of
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // tiles need no masking in m and n, only in-bounds addresses (clamped below; for an m-contiguous operand the last
         // 16-byte pair may read the padding element at column X, which exists because the leading dimension is even).
         const bool fast = g.vecA && g.vecB;
-        const int nkf = fast ? g.K / BK : kt0;                        // full slabs
+        const int nkf = fast ? Kt / BK : kt0;                         // full slabs
         if (nkf > kt0) {
             const int t = threadIdx.x;
             const double* pa[NA]; const double* pb[NB];
@@ -282,16 +285,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     if (kdone < nk) {                                                 // edge tiles, unaligned operands, the partial slab
         d2 ra[NA], rb[NB];
-        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kdone * BK, g.K, g.vecA, ra);
-        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kdone * BK, g.K, g.vecB, rb);
+        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kdone * BK, Kt, g.vecA, ra);
+        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kdone * BK, Kt, g.vecB, rb);
         store_tile<!TA, BM>(As + (kdone & 1) * A_SZ, ra);
         store_tile<TB, BN>(Bs + (kdone & 1) * B_SZ, rb);
         __syncthreads();
         for (int kt = kdone; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) {
-                load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, g.vecA, ra);
-                load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, g.vecB, rb);
+                load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, Kt, g.vecA, ra);
+                load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, Kt, g.vecB, rb);
             }
             compute(cur);
             if (kt + 1 < nk) {
@@ -469,6 +472,7 @@ extern "C" int gpk_debug_set_strip(int v);
 extern "C" int gpk_debug_set_fused_trsv(int v);
 extern "C" int gpk_debug_set_fused_panel(int v);
 extern "C" int gpk_debug_set_persistent_ob(int v);
+extern "C" int gpk_debug_set_use_dinv(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -480,11 +484,12 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 8) { g_k64_small = value; return 0; }
     if (key == 9) { g_gemm_extra_lds = value; return 0; }
     if (key == 6) { g_supertile = value; return 0; }
+    if (key == 10) return gpk_debug_set_use_dinv(value);
     return GPK_ERR_ARG;
 }
 
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
-               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead) {
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead, bool tri_a) {
     if (m <= 0 || n <= 0) return 0;
     if (k < 0 || !A || !B || !C) return gpk_bad_arg(h, "gemm: sizes/pointers");
     if (lower_only && m != n) return gpk_bad_arg(h, "gemm: lower_only needs a square C");
@@ -493,9 +498,10 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.lower_only = lower_only ? 1 : 0;
     g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
+    g.tri_a = (tri_a && !ta && !lower_only) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
-    if (k <= 64 && !lower_only && g_force_cfg == 0 &&
+    if (k <= 64 && !lower_only && !g.tri_a && g_force_cfg == 0 &&
         (beta == 0.0 || (beta == 1.0 && (alpha == 1.0 || alpha == -1.0))))
         return launch_k64(h, ta, tb, g);
     // The 64x64 configuration (4 workgroups per CU, two slabs in flight) is used for every shape: with the straight-line

@@ -15,7 +15,7 @@
 
 namespace {
 
-struct Group { const double* L; int ldl; int n; int off; };
+struct Group { const double* L; int ldl; int n; int off; const double* Dinv; };
 
 struct Dims { int nz; int rows; int ngroups; Group g[3]; };
 
@@ -24,21 +24,21 @@ int gn_dims(const gpk_gn_problem* p, Dims& d) {
     if (Nd <= 0 || Nb < 0) return GPK_ERR_ARG;
     switch (p->system) {
         case GPK_GN_ELLIPTIC:
-            d.nz = Nd; d.ngroups = 1; d.g[0] = {p->L, p->ldl, 2 * Nd + Nb, 0}; d.rows = 2 * Nd + Nb; break;
+            d.nz = Nd; d.ngroups = 1; d.g[0] = {p->L, p->ldl, 2 * Nd + Nb, 0, p->Dinv}; d.rows = 2 * Nd + Nb; break;
         case GPK_GN_BURGERS:
         case GPK_GN_EIKONAL:
-            d.nz = 3 * Nd; d.ngroups = 1; d.g[0] = {p->L, p->ldl, 4 * Nd + Nb, 0}; d.rows = 4 * Nd + Nb; break;
+            d.nz = 3 * Nd; d.ngroups = 1; d.g[0] = {p->L, p->ldl, 4 * Nd + Nb, 0, p->Dinv}; d.rows = 4 * Nd + Nb; break;
         case GPK_GN_DARCY:
             if (p->Ndata < 0 || p->Ndata > Nd) return GPK_ERR_ARG;
             d.nz = 6 * Nd; d.ngroups = 3;
-            d.g[0] = {p->L2, p->ldl2, 3 * Nd, 0};
-            d.g[1] = {p->L, p->ldl, 4 * Nd + Nb, 3 * Nd};
-            d.g[2] = {nullptr, 0, p->Ndata, 7 * Nd + Nb};
+            d.g[0] = {p->L2, p->ldl2, 3 * Nd, 0, p->Dinv2};
+            d.g[1] = {p->L, p->ldl, 4 * Nd + Nb, 3 * Nd, p->Dinv};
+            d.g[2] = {nullptr, 0, p->Ndata, 7 * Nd + Nb, nullptr};
             d.rows = 7 * Nd + Nb + p->Ndata; break;
         case GPK_GN_ELLIPTIC_RELAXED:
             d.nz = 2 * Nd; d.ngroups = 2;
-            d.g[0] = {p->L, p->ldl, 2 * Nd + Nb, 0};
-            d.g[1] = {nullptr, 0, Nd, 2 * Nd + Nb};
+            d.g[0] = {p->L, p->ldl, 2 * Nd + Nb, 0, p->Dinv};
+            d.g[1] = {nullptr, 0, Nd, 2 * Nd + Nb, nullptr};
             d.rows = 3 * Nd + Nb; break;
         default: return GPK_ERR_ARG;
     }
@@ -171,26 +171,52 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
     return 0;
 }
 
+int g_use_dinv = 1;                  // gpk_debug_set key 10: 0 = substitution strips even when the inverses are supplied
+
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } while (0)
 
 // S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered).
 // rev != 0 (elliptic system only): unknown j is stored in column nz-1-j; column c < nz of [A | F] is then zero above row
 // nz-1-c, which the solve and the SYRK exploit (about a third of the TRSM flops and a quarter of the SYRK flops).
+// With the inverses of the diagonal blocks of every factor at hand (gpk_trtri_diag, gpk_gn_problem::Dinv) the solve runs
+// out of place into the handle's workspace W (all-GEMM, see gpk_i_trsm_left_dinv) and the SYRK reads W; S is scratch then.
 int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, double* S, int lds,
                               double* Hb, int ldh, double alpha, int rev) {
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
+    bool dinv = g_use_dinv != 0;
+    for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) dinv = false;
+    double* W = S;
+    if (dinv) {
+        GPK_TRY(gpk_i_workspace(h, (size_t)d.rows * lds * sizeof(double), &W));
+        // the solve never writes W left of the leading-zero boundary (rev) -- zero it unless the previous solve into W had
+        // exactly this shape, in which case those zeros are still there
+        const long sig[5] = {d.rows, lds, nc, rev ? d.nz : 0, p->system + 1};
+        if (memcmp(sig, h->work_sig, sizeof sig) != 0) {
+            GPK_HIP(h, hipMemsetAsync(W, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
+            memcpy(h->work_sig, sig, sizeof sig);
+        }
+    }
     GPK_PROF_MARK(h, 0);
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
     GPK_TRY(build(h, p, z, S, lds, d.nz, 1, rev));
-    if (rev) {
-        GPK_TRY(gpk_i_trsm_left_lz(h, d.g[0].L, d.g[0].n, d.g[0].ldl, S, nc, lds, d.nz, 0));
-    } else {
-        for (int k = 0; k < d.ngroups; ++k)
-            if (d.g[k].L) GPK_TRY(gpk_i_trsm_left_mt(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, S + (long)d.g[k].off * lds, nc, lds));
+    for (int k = 0; k < d.ngroups; ++k) {
+        const Group& g = d.g[k];
+        double* Sg = S + (long)g.off * lds;
+        if (!g.L) {                                                  // identity factor (data misfit / penalty rows)
+            if (dinv && g.n > 0)
+                GPK_HIP(h, hipMemcpy2DAsync(W + (long)g.off * lds, (size_t)lds * 8, Sg, (size_t)lds * 8, (size_t)nc * 8, g.n,
+                                            hipMemcpyDeviceToDevice, h->stream));
+        } else if (dinv) {
+            GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, g.n, g.ldl, Sg, lds, W + (long)g.off * lds, lds, nc, rev ? d.nz : 0, 0));
+        } else if (rev) {
+            GPK_TRY(gpk_i_trsm_left_lz(h, g.L, g.n, g.ldl, Sg, nc, lds, d.nz, 0));
+        } else {
+            GPK_TRY(gpk_i_trsm_left_mt(h, false, g.L, g.n, g.ldl, Sg, nc, lds));
+        }
     }
     GPK_PROF_MARK(h, 1);
-    GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, S, lds, S, lds, 0.0, Hb, ldh, true, rev ? d.nz : 0));
+    GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, W, lds, W, lds, 0.0, Hb, ldh, true, rev ? d.nz : 0));
     GPK_PROF_MARK(h, 2);
     return 0;
 }
@@ -309,3 +335,5 @@ extern "C" int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* p, const d
     GPK_HIP(h, hipMemsetAsync(out, 0, (size_t)d.rows * sizeof(double), h->stream));
     return build(h, &q, z, out, 1, 0, 0);
 }
+
+extern "C" int gpk_debug_set_use_dinv(int v) { g_use_dinv = v; return 0; }

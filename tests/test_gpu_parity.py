@@ -187,6 +187,40 @@ def test_trsm(ctx, trans, n, nrhs):
     assert np.linalg.norm(op @ X - B) <= 1e-12 * np.linalg.norm(L) * np.linalg.norm(X)
 
 
+@pytest.mark.parametrize('n,nrhs,lead', [(64, 64, 0), (256, 100, 0), (300, 77, 0), (1000, 257, 0), (1537, 1001, 0), (2360, 1101, 1100),
+                                         (1924, 901, 900), (700, 650, 649), (513, 300, 200)])
+def test_trsm_dinv(ctx, n, nrhs, lead):
+    """All-GEMM forward solve through the explicit inverses of the 256-wide diagonal blocks (gpk_trtri_diag + gpk_trsm_dinv)
+    against numpy and against the substitution path; lead > 0: right-hand sides with the leading-zero shape of [A | F]."""
+    rng = np.random.RandomState(n + nrhs)
+    L = np.tril(rng.normal(size=(n, n))) + np.diag(rng.uniform(3, 4, n) * np.sqrt(n))
+    B = rng.normal(size=(n, nrhs))
+    if lead:
+        rows = np.arange(n)[:, None]; cols = np.arange(nrhs)[None, :]
+        B[(cols < lead) & (rows < lead - 1 - cols)] = 0.0
+    dL = ctx.array(L)
+    D = ctx.trtri_diag(dL)
+    Dh = D.download()
+    for k0 in range(0, n, 256):                                   # each block: inverse of the diagonal block, exact zeros above
+        nk = min(256, n - k0)
+        blk = Dh[k0:k0 + nk, :nk]
+        assert np.all(np.triu(blk, 1) == 0.0)
+        assert np.linalg.norm(L[k0:k0 + nk, k0:k0 + nk] @ blk - np.eye(nk)) <= 1e-12 * nk
+    dB = ctx.array(B)
+    dX = ctx.empty(n, nrhs); dX.zero()
+    ctx.trsm_dinv(dL, D, dB, dX, lead=lead)
+    X = dX.download().reshape(n, nrhs)
+    assert np.linalg.norm(L @ X - B) <= 1e-12 * np.linalg.norm(L) * np.linalg.norm(X)
+    dB2 = ctx.array(B)
+    ctx.trsm(dL, dB2)
+    X2 = dB2.download().reshape(n, nrhs)
+    assert np.linalg.norm(X - X2) <= 1e-12 * np.linalg.norm(X2)
+    if lead:                                                      # structural zeros of the solution stay exact zeros
+        assert np.all(X[(cols < lead) & (rows < lead - 1 - cols)] == 0.0)
+    with pytest.raises(Exception):
+        ctx.trsm_dinv(dL, D, dB, dB)                              # aliasing is refused
+
+
 @pytest.mark.parametrize('n', [1, 64, 100, 1000, 3001])
 def test_trsv_and_potrs(ctx, n):
     rng = np.random.RandomState(n)

@@ -18,8 +18,10 @@ VARIANTS = [
     ('supertile schedule of the leading-zero SYRK', {6: 1}),
     ('128x128 GEMM tiles', {0: 1}),
     ('persistent outer-block Cholesky kernel (flag-chained workgroups)', {7: 1}),
+    ('substitution strips instead of the inverted diagonal blocks', {10: 0}),
+    ('substitution, 64-row base solves', {10: 0, 3: 0}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
