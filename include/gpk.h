@@ -111,14 +111,14 @@ int gpk_gemm_lz(gpk_handle h, int ta, int m, int n, int k, double alpha, const d
                 const double* B, int ldb, double beta, double* C, int ldc, int lead);
 /* Companion of a Cholesky factor that is reused for many multi-right-hand-side forward solves (the factor of Theta in
  * GN_method: jnp.linalg.solve(self.L, .) inside every Hessian_GN, src/PDEs.py:97,306,450; src/InverseProblems.py:145-146):
- * Dinv (n x 256 doubles, leading dimension 256) receives the inverses of the 256 x 256 diagonal blocks of L, block k in rows
- * [256k, 256k + n_k), computed by substitution.  gpk_trsm_dinv then solves L X = B with GEMMs only: X (n x nrhs, ld ldx, must
- * not alias B) receives L^{-1} B, B is overwritten with intermediate values.  lead > 0: column c < lead of B is zero above row
- * lead-1-c (as gpk_trsm_lz); the zero part of X left of that boundary is NOT written, so X must be zero there on entry
- * (zero X once; solves of the same shape keep it valid).  Accuracy: DESIGN.md section 4 (measured 5e-14 relative on the
- * Gauss-Newton iterates at nugget 1e-13). */
-int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv);
-int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int nrhs, int ldb,
+ * Dinv (n x block doubles, leading dimension block; block = 256, 512 or 1024) receives the inverses of the block x block
+ * diagonal blocks of L, block k in rows [k block, k block + n_k), computed by substitution.  gpk_trsm_dinv then solves
+ * L X = B with GEMMs only: X (n x nrhs, ld ldx, must not alias B) receives L^{-1} B, B is overwritten with intermediate
+ * values.  lead > 0: column c < lead of B is zero above row lead-1-c (as gpk_trsm_lz); the zero part of X left of that
+ * boundary is NOT written, so X must be zero there on entry (zero X once; solves of the same shape keep it valid).
+ * Accuracy: DESIGN.md section 4 (Gauss-Newton iterates within 3e-13 of the substitution path at nugget 1e-13, config 2). */
+int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int block);
+int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int block, int n, int ldl, double* B, int nrhs, int ldb,
                   double* X, int ldx, int lead);
 /* C <- alpha*A^T A + beta*C, A is k x n row-major; lower triangle only unless full != 0
  * (the 2*ss^T ss of src/PDEs.py:307 and of every autodiff Hessian_GN). */
@@ -137,6 +137,7 @@ typedef struct {
     const double* L2; int ldl2;    /* DARCY: L_a */
     const double* Dinv;            /* optional (may be NULL): gpk_trtri_diag(L)  -- the S solve then runs as GEMMs only */
     const double* Dinv2;           /* optional, DARCY: gpk_trtri_diag(L2) */
+    int dinv_block;                /* block size Dinv / Dinv2 were built with (0 = 256) */
 } gpk_gn_problem;
 
 /* sizes: nz unknowns, rows of the stacked S = [L^{-1}A | L^{-1}F] buffer */

@@ -66,10 +66,10 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
 int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead, int row0);
 // same, right-hand sides split into independent column groups that run on concurrent streams
 int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
-// explicit inverses of the 256 x 256 diagonal blocks of L (Dinv: n x 256, ld 256) and the all-GEMM forward solve built on
-// them: X <- L^{-1} B out of place, B is scratch afterwards (see gpk_factor.hip)
-int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv);
-int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int ldb,
+// explicit inverses of the db x db diagonal blocks of L (Dinv: n x db, ld db; db = 256, 512 or 1024) and the all-GEMM forward
+// solve built on them: X <- L^{-1} B out of place, B is scratch afterwards (see gpk_factor.hip)
+int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db);
+int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int db, int n, int ldl, double* B, int ldb,
                          double* X, int ldx, int nrhs, int lead, int row0);
 int gpk_i_workspace(gpk_handle h, size_t bytes, double** out);                          // handle-owned scratch, grown on demand
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);

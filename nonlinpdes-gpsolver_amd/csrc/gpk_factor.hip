@@ -390,8 +390,11 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
 // (the counter is never reset: the host passes the cumulative number of tickets).  Nobody ever waits for workgroup 0.
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, long lda, int nb, int below,
                                                           int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
+    // 37.4 KB of LDS in total: must stay below the 40 KB of a GEMM workgroup (four of those fill a CU's 160 KB), so that a
+    // panel workgroup fits into the slot a retiring GEMM workgroup frees when both run concurrently
     __shared__ double As[NB * XS];
-    __shared__ __attribute__((aligned(16))) double Ps[NB * RB];
+    __shared__ __attribute__((aligned(16))) double Ps[8 * NB];       // potf2_tile's column exchange: 2 parities x 4 vectors
+    __builtin_amdgcn_s_setprio(3);                                   // latency chain: win issue arbitration against co-resident GEMM waves
     const int c0 = ((int)blockIdx.x - 1) * NB;                       // blocks > 0: my 64 rows below the diagonal block
     double xr[16];
     if (blockIdx.x > 0) potf2_fetch_extra(A + (long)(nb + c0) * lda, lda, min(NB, below - c0), nb, xr);   // same round trip as A_jj
@@ -1037,47 +1040,54 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
 // The factor L of Theta is fixed for the whole Gauss-Newton iteration while S = L^{-1}[A | F] is recomputed every step, and
 // in that solve the only work that is not a GEMM is the 256-row strip substitution: a latency chain (33 strips x 33 us =
 // 1.1 ms of the 4.3 ms TRSM phase at BASELINE config 2).  gpk_trtri_diag computes, ONCE per factor and by the same true
-// substitution (strip kernel on an identity right-hand side), the inverses of the 256 x 256 diagonal blocks; the strip solve
-// then is X_k = inv(L_kk) B_k, a GEMM with a lower-triangular operand (K loop cut at the diagonal per row tile), and the
-// whole TRSM runs on the matrix cores.  This is what MAGMA / rocBLAS do for trsm; it is only conditionally stable, so it was
+// substitution (the substitution solve on an identity right-hand side), the inverses of the db x db diagonal blocks (db = 256,
+// 512 or 1024); the solve of a block row then is X_k = inv(L_kk) B_k, a GEMM with a lower-triangular operand (K loop cut at the
+// diagonal per row tile), and the whole TRSM runs on the matrix cores.  Larger blocks replace the small, launch-bound GEMMs at
+// the bottom of the recursion by one well-filled triangular product (same flops): 3.64 -> see DESIGN.md for db = 1024.  This is what MAGMA / rocBLAS do for trsm; it is only conditionally stable, so it was
 // checked on this problem class before being adopted: the residual of inv(L_kk) B_k is bounded by eps cond(L_kk) |B_k| instead
 // of eps |L_kk| |X_k|, which is the same size whenever X is large relative to B -- the case here (|L^{-1}A| ~ 1e8).  Measured
 // with the CPU oracle at nugget 1e-13 (cond(L) = 1.8e9, diagonal blocks up to 1.5e7): Gauss-Newton iterates differ from the
-// substitution path by 8e-14 (config 1) and 5e-14 (config 2) relative; 1024-wide blocks would give 3e-10, still far inside
-// the 1e-6 parity bound.  Only the diagonal BLOCKS are inverted; L itself never is.
+// substitution path by 8e-14 / 3e-13 / 3e-10 (config 1: N = 1924, db = 256 / 512 / 1024 -- the last is more than half of the
+// matrix, block condition 1.7e9) and 5e-14 / 1.3e-13 / 2.6e-13 (config 2: N = 8400, blocks up to 2.9e7), against a parity bound
+// of 1e-6 and 5e-9 between equally valid fp64 implementations.  Only the diagonal BLOCKS are inverted; L never is.
 // Out of place: the leaf writes X_k = inv(L_kk) B_k into a second buffer (a GEMM cannot run in place over its K range), the
 // updates B_2 -= L_21 X_1 read X and modify B, so on return X holds the solution and B is scratch.
-__global__ void dinv_identity_kernel(double* __restrict__ D, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;                    // one thread per entry of the n x DB array
-    if (i < n * SB) D[i] = ((i / SB) % SB == i % SB) ? 1.0 : 0.0;
+__global__ void dinv_identity_kernel(double* __restrict__ D, int n, int db) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;             // one thread per entry of the n x db array
+    if (i < (long)n * db) D[i] = ((i / db) % db == i % db) ? 1.0 : 0.0;
 }
 
-int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv) {
+inline bool dinv_block_ok(int db) { return db == 256 || db == 512 || db == 1024; }
+
+int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db) {
     if (n <= 0) return 0;
-    dinv_identity_kernel<<<gpk_ceil_div(n * SB, 256), 256, 0, h->stream>>>(Dinv, n);
+    if (!dinv_block_ok(db)) return gpk_bad_arg(h, "trtri_diag: block size must be 256, 512 or 1024");
+    dinv_identity_kernel<<<(unsigned)(((long)n * db + 255) / 256), 256, 0, h->stream>>>(Dinv, n, db);
     GPK_LAUNCH_CHECK(h);
-    for (int k0 = 0; k0 < n; k0 += SB) {
-        const int nk = (n - k0 < SB) ? n - k0 : SB;
+    for (int k0 = 0; k0 < n; k0 += db) {
+        const int nk = (n - k0 < db) ? n - k0 : db;
         // (substitution keeps the zeros above the diagonal of the inverse exact: x_i = (0 - sum 0) / l_ii)
-        GPK_TRY(gpk_i_trsm_left(h, false, L + (long)k0 * ldl + k0, nk, ldl, Dinv + (long)k0 * SB, nk, SB));
+        GPK_TRY(gpk_i_trsm_left(h, false, L + (long)k0 * ldl + k0, nk, ldl, Dinv + (long)k0 * db, nk, db));
     }
     return 0;
 }
 
-int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int ldb,
+int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int db, int n, int ldl, double* B, int ldb,
                          double* X, int ldx, int nrhs, int lead, int row0) {
     if (n <= 0 || nrhs <= 0) return 0;
     int clo = lead - (row0 + n);                                     // (lead = 0: dense right-hand sides)
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
-    if (n <= SB) {
+    if (n <= db) {
         const int lz = lead - row0 - clo;
-        return gpk_i_gemm(h, false, false, n, nrhs - clo, n, 1.0, Dinv + (long)row0 * SB, SB, B + clo, ldb, 0.0, X + clo, ldx,
+        return gpk_i_gemm(h, false, false, n, nrhs - clo, n, 1.0, Dinv + (long)row0 * db, db, B + clo, ldb, 0.0, X + clo, ldx,
                           false, lz > 0 ? lz : 0, true);
     }
-    const int n1 = split(n, SB), n2 = n - n1;
+    int n1 = ((n / 2 + db - 1) / db) * db;                           // first part: about half, a multiple of the block size
+    if (n1 >= n) n1 = db;
+    const int n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
-    GPK_TRY(gpk_i_trsm_left_dinv(h, L, Dinv, n1, ldl, B, ldb, X, ldx, nrhs, lead, row0));
+    GPK_TRY(gpk_i_trsm_left_dinv(h, L, Dinv, db, n1, ldl, B, ldb, X, ldx, nrhs, lead, row0));
     int c1 = lead - (row0 + n1);                                     // X[rows of part 1] is zero left of this column
     c1 = c1 > 0 ? (c1 / NB) * NB : 0;
     if (c1 < nrhs) {
@@ -1085,7 +1095,7 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
         GPK_TRY(gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, X + c1, ldx, 1.0, B + (long)n1 * ldb + c1, ldb,
                            false, lz > 0 ? lz : 0));
     }
-    return gpk_i_trsm_left_dinv(h, L21 + n1, Dinv, n2, ldl, B + (long)n1 * ldb, ldb, X + (long)n1 * ldx, ldx, nrhs, lead, row0 + n1);
+    return gpk_i_trsm_left_dinv(h, L21 + n1, Dinv, db, n2, ldl, B + (long)n1 * ldb, ldb, X + (long)n1 * ldx, ldx, nrhs, lead, row0 + n1);
 }
 
 // The 64-row diagonal solves of a multi-RHS TRSM keep only nrhs/64 waves busy and sit on the critical path between
@@ -1213,6 +1223,7 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     return 0;
 }
 
+int g_probe_chain_cus = 0;                                           // gpk_debug_set key 11: overlap probe with a CU-mask partition
 int g_fused_trsv = 1;                                                 // gpk_debug_set key 4: 0 = two launches per block
 
 int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x) {
@@ -1260,6 +1271,7 @@ extern "C" int gpk_debug_set_strip(int v) { g_strip = v; return 0; }
 extern "C" int gpk_debug_set_fused_trsv(int v) { g_fused_trsv = v; return 0; }
 extern "C" int gpk_debug_set_fused_panel(int v) { g_fused_panel = v; return 0; }
 extern "C" int gpk_debug_set_persistent_ob(int v) { g_persistent_ob = v; return 0; }
+extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;
@@ -1302,16 +1314,17 @@ extern "C" int gpk_trsm_lz(gpk_handle h, const double* L, int n, int ldl, double
     return gpk_i_trsm_left_lz(h, L, n, ldl, B, nrhs, ldb, lead, 0);
 }
 
-extern "C" int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv) {
+extern "C" int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int block) {
     if (!h || !L || !Dinv || n < 0 || ldl < n) return GPK_ERR_ARG;
-    return gpk_i_trtri_diag(h, L, n, ldl, Dinv);
+    return gpk_i_trtri_diag(h, L, n, ldl, Dinv, block);
 }
 
-extern "C" int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int n, int ldl, double* B, int nrhs, int ldb,
+extern "C" int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int block, int n, int ldl, double* B, int nrhs, int ldb,
                              double* X, int ldx, int lead) {
     if (!h || !L || !Dinv || !B || !X || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs || ldx < nrhs) return GPK_ERR_ARG;
+    if (!dinv_block_ok(block)) return gpk_bad_arg(h, "trsm_dinv: block size must be 256, 512 or 1024");
     if (B == X) return gpk_bad_arg(h, "trsm_dinv: X must not alias B");
-    return gpk_i_trsm_left_dinv(h, L, Dinv, n, ldl, B, ldb, X, ldx, nrhs, lead > 0 ? lead : 0, 0);
+    return gpk_i_trsm_left_dinv(h, L, Dinv, block, n, ldl, B, ldb, X, ldx, nrhs, lead > 0 ? lead : 0, 0);
 }
 
 extern "C" int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {
@@ -1330,9 +1343,21 @@ extern "C" int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* 
 extern "C" int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,
                                        double* host_ms3) {
     if (!h || !H || !S || !C2 || !host_ms3) return GPK_ERR_ARG;
-    hipStream_t side = nullptr, main_s = h->stream;
+    hipStream_t side = nullptr, main_s = h->stream, chain = nullptr;
+    const hipStream_t restore = h->stream;
     int lo = 0, hi = 0;
     GPK_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    if (g_probe_chain_cus > 0) {
+        // spatial partition: the chain (potrf) stream gets the first g_probe_chain_cus bits of the CU mask (bit i -> XCD i % 8 on
+        // this chip, so a multiple of 8 takes the same number of CUs from every XCD), the GEMM stream gets the rest
+        uint32_t ma[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mb[8];
+        for (int i = 0; i < g_probe_chain_cus && i < 256; ++i) ma[i >> 5] |= 1u << (i & 31);
+        for (int i = 0; i < 8; ++i) mb[i] = ~ma[i];
+        GPK_HIP(h, hipExtStreamCreateWithCUMask(&chain, 8, ma));
+        GPK_HIP(h, hipExtStreamCreateWithCUMask(&side, 8, mb));
+        main_s = chain;
+        h->stream = chain;
+    } else
     GPK_HIP(h, hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
     hipEvent_t e0, e1, ef;
     GPK_HIP(h, hipEventCreate(&e0)); GPK_HIP(h, hipEventCreate(&e1)); GPK_HIP(h, hipEventCreateWithFlags(&ef, hipEventDisableTiming));
@@ -1359,6 +1384,8 @@ extern "C" int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, 
         host_ms3[mode] = ms;
     }
     GPK_HIP(h, hipFree(Hc));
+    h->stream = restore;
+    if (chain) GPK_HIP(h, hipStreamDestroy(chain));
     GPK_HIP(h, hipStreamDestroy(side));
     GPK_HIP(h, hipEventDestroy(e0)); GPK_HIP(h, hipEventDestroy(e1)); GPK_HIP(h, hipEventDestroy(ef));
     return 0;

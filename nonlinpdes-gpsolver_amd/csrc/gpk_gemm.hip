@@ -45,6 +45,7 @@ struct GemmArgs {
                        // with rows [m0, m0+BM) stops its K loop at m0+BM (the explicit inverses of diagonal blocks, gpk_trsm_dinv)
     int vecA, vecB;
     int ntm, ntn, ntiles;
+    int ntm_full;      // tri_a: number of row tiles of C (ntm counts PAIRS of them then)
     int nsuper;        // > 0: supertile schedule of the lower-triangular, leading-zero (SYRK) launch, see map_tile
 };
 
@@ -171,7 +172,7 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& tm, int& tn) {
     return true;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB>
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool TRI = false>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr bool PF2 = (BM * BN <= 64 * 64);                      // prefetch depth 2 for the small-tile configuration
@@ -183,12 +184,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     double* const As = smem;
     double* const Bs = smem + 2 * A_SZ;
 
-    int tm, tn;
-    if (!map_tile(g, tm, tn)) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int tm_map, tn;
+    if (!map_tile(g, tm_map, tn)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int li = lane & 15, lk = lane >> 4;
+    const int n0 = tn * BN;
+    // Lower-triangular A (tri_a): the K loop of row tile t ends at (t+1) BM, so tile t costs ~(t+1) units.  The grid then has
+    // one workgroup per PAIR of row tiles (t, ntm_full-1-t) -- constant work per workgroup whatever the dispatcher does (with
+    // one tile per workgroup, the four tiles a CU received had the same t: 4..64 slabs against an average of 34).
+    // (TRI is a template parameter and the tile body a lambda: as a runtime loop around the body it cost every instantiation
+    // 30-50 VGPRs and a wave of occupancy)
+    auto tile = [&](const int tm) __attribute__((always_inline)) {
+    const int m0 = tm * BM;
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    const int Kt = g.tri_a ? min(g.K, m0 + BM) : g.K;                 // lower-triangular A: nothing right of the tile's last row
+    const int Kt = TRI ? min(g.K, m0 + BM) : g.K;                     // lower-triangular A: nothing right of the tile's last row
     const int nk = (Kt + BK - 1) / BK;
     int kt0 = 0;
     if (g.lead > 0) {                                                 // both operands are zero above this row (tm >= tn)
@@ -324,6 +332,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             }
         }
     }
+    };
+    if (TRI) {
+        const int hi = g.ntm_full - 1 - tm_map;                       // the long tile first
+        tile(hi);
+        if (hi != tm_map) tile(tm_map);                               // odd count: the middle tile is its own partner
+    } else {
+        tile(tm_map);
+    }
 }
 
 // ---- rank-<=64 updates: everything in flight at once -----------------------------------------------------------------
@@ -339,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) double smem[NK * (A_SZ + B_SZ)];
     double* const As = smem;
     double* const Bs = smem + NK * A_SZ;
+    __builtin_amdgcn_s_setprio(3);                                   // part of a latency chain (panel loop): see potrf_panel_kernel
     int tm, tn;
     if (!map_tile(g, tm, tn)) return;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -432,6 +449,8 @@ int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.ntm = gpk_ceil_div(g.M, BM);
+    g.ntm_full = g.ntm;
+    if (g.tri_a) g.ntm = (g.ntm + 1) / 2;                            // one workgroup per pair of row tiles (see the kernel)
     g.ntn = gpk_ceil_div(g.N, BN);
     g.ntiles = g.lower_only ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
     g.nsuper = 0;
@@ -443,7 +462,8 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     }
     dim3 grid(nblocks), block(256);
     const size_t dyn = (size_t)g_gemm_extra_lds;
-    if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, dyn, h->stream>>>(g);
+    if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true><<<grid, block, dyn, h->stream>>>(g);   // (only NN reaches here)
+    else if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, dyn, h->stream>>>(g);
     else if (!ta && tb) gemm_f64_kernel<BM, BN, WM, WN, false, true><<<grid, block, dyn, h->stream>>>(g);
     else if (ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, true, false><<<grid, block, dyn, h->stream>>>(g);
     else gemm_f64_kernel<BM, BN, WM, WN, true, true><<<grid, block, dyn, h->stream>>>(g);
@@ -473,6 +493,7 @@ extern "C" int gpk_debug_set_fused_trsv(int v);
 extern "C" int gpk_debug_set_fused_panel(int v);
 extern "C" int gpk_debug_set_persistent_ob(int v);
 extern "C" int gpk_debug_set_use_dinv(int v);
+extern "C" int gpk_debug_set_probe_chain_cus(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -485,6 +506,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 9) { g_gemm_extra_lds = value; return 0; }
     if (key == 6) { g_supertile = value; return 0; }
     if (key == 10) return gpk_debug_set_use_dinv(value);
+    if (key == 11) return gpk_debug_set_probe_chain_cus(value);
     return GPK_ERR_ARG;
 }
 
@@ -498,7 +520,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.lower_only = lower_only ? 1 : 0;
     g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
-    g.tri_a = (tri_a && !ta && !lower_only) ? 1 : 0;
+    g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
     if (k <= 64 && !lower_only && !g.tri_a && g_force_cfg == 0 &&
@@ -508,11 +530,12 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // two-slab prefetch it beats the 128x128 one (2 per CU, 232 VGPRs, one slab in flight) from 2048 to 21000 on every
     // operand layout (tools/gemm_big_probe.py: 62.0 vs 58.8 TF/s NN 10500^3-ish, 58.6 vs 49.8 NT K=512).  The large
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
-    const bool big = (g_force_cfg == 1);
+    const bool big = (g_force_cfg == 1) && !g.tri_a;
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
     // short-and-wide updates of the triangular-solve recursion (M = 256 or 512 against ~4000 columns): 64x64 tiles give
     // only 1-2 workgroups per CU, i.e. one wave per SIMD and nothing to hide latency behind; 32x64 tiles double that
-    const long t64 = (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64);
+    long t64 = (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64);
+    if (g.tri_a) t64 /= 2;                                            // workgroups handle pairs of row tiles
     if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
     return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
 }

@@ -185,6 +185,8 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
     bool dinv = g_use_dinv != 0;
+    const int db = p->dinv_block > 0 ? p->dinv_block : 256;
+    if (db != 256 && db != 512 && db != 1024) return gpk_bad_arg(h, "gn: dinv_block must be 256, 512 or 1024");
     for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) dinv = false;
     double* W = S;
     if (dinv) {
@@ -208,7 +210,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
                 GPK_HIP(h, hipMemcpy2DAsync(W + (long)g.off * lds, (size_t)lds * 8, Sg, (size_t)lds * 8, (size_t)nc * 8, g.n,
                                             hipMemcpyDeviceToDevice, h->stream));
         } else if (dinv) {
-            GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, g.n, g.ldl, Sg, lds, W + (long)g.off * lds, lds, nc, rev ? d.nz : 0, 0));
+            GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, db, g.n, g.ldl, Sg, lds, W + (long)g.off * lds, lds, nc, rev ? d.nz : 0, 0));
         } else if (rev) {
             GPK_TRY(gpk_i_trsm_left_lz(h, g.L, g.n, g.ldl, Sg, nc, lds, d.nz, 0));
         } else {

@@ -15,7 +15,7 @@ class GNProblemStruct(C.Structure):
                 ('p0', C.c_double), ('p1', C.c_double), ('pen_lambda', C.c_double),
                 ('rhs_f', C.c_void_p), ('bdy_g', C.c_void_p), ('data_u', C.c_void_p),
                 ('L', C.c_void_p), ('ldl', C.c_int), ('L2', C.c_void_p), ('ldl2', C.c_int),
-                ('Dinv', C.c_void_p), ('Dinv2', C.c_void_p)]
+                ('Dinv', C.c_void_p), ('Dinv2', C.c_void_p), ('dinv_block', C.c_int)]
 
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
@@ -53,8 +53,8 @@ PROTOTYPES = {
     'gpk_potrf_panel': (_i, [_vp, _vp, _i, _i, _i, _pi]),
     'gpk_trsm': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
     'gpk_trsm_lz': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i]),
-    'gpk_trtri_diag': (_i, [_vp, _vp, _i, _i, _vp]),
-    'gpk_trsm_dinv': (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _i]),
+    'gpk_trtri_diag': (_i, [_vp, _vp, _i, _i, _vp, _i]),
+    'gpk_trsm_dinv': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i]),
     'gpk_gemm_lz': (_i, [_vp, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i, _i]),
     'gpk_trsm_right_lt': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),
     'gpk_potrs': (_i, [_vp, _vp, _i, _i, _vp, _i, _i]),

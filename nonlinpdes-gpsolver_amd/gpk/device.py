@@ -10,6 +10,7 @@ from ._lib import GNProblemStruct, GpkError, load_library
 LAYOUT = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_u': 2, 'Darcy_a': 3}
 KERNEL = {'Gaussian': 0, 'anisotropic_Gaussian': 1}
 NUGGET = {'none': 0, 'identity': 1, 'adaptive': 2}
+DINV_BLOCK = int(__import__('os').environ.get('GPK_DINV_BLOCK', '1024'))   # rows per inverted diagonal block of a factor (256, 512, 1024)
 SYSTEM = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_flow2d': 3, 'Nonlinear_elliptic_relaxed': 4}
 
 
@@ -88,8 +89,8 @@ class GNProblem:
     """Device-side description of one equation's Gauss-Newton system (gpk_gn_problem)."""
 
     def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True):
-        """dinv: also compute the inverses of the 256-wide diagonal blocks of the factor(s) once (gpk_trtri_diag), so that
-        the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
+        """dinv: also compute the inverses of the diagonal blocks of the factor(s) once (gpk_trtri_diag; True = blocks of
+        DINV_BLOCK rows, or 256 / 512 / 1024), so that the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
         self.ctx = ctx
         self.keep = []
         def dev(v):
@@ -109,10 +110,12 @@ class GNProblem:
         s.data_u = self.data_u.ptr if self.data_u is not None else None
         s.L, s.ldl = L.ptr, L.ld
         s.L2, s.ldl2 = (L2.ptr, L2.ld) if L2 is not None else (None, 0)
-        self.Dinv = ctx.trtri_diag(L) if dinv else None
-        self.Dinv2 = ctx.trtri_diag(L2) if (dinv and L2 is not None) else None
+        block = DINV_BLOCK if dinv is True else int(dinv)
+        self.Dinv = ctx.trtri_diag(L, block=block) if dinv else None
+        self.Dinv2 = ctx.trtri_diag(L2, block=block) if (dinv and L2 is not None) else None
         s.Dinv = self.Dinv.ptr if self.Dinv is not None else None
         s.Dinv2 = self.Dinv2.ptr if self.Dinv2 is not None else None
+        s.dinv_block = block if dinv else 0
         self.struct = s
         nz, rows = C.c_int(), C.c_int()
         ctx._chk(ctx.lib.gpk_gn_dims(C.byref(s), C.byref(nz), C.byref(rows)))
@@ -257,18 +260,19 @@ class Context:
         nrhs = B.cols if nrhs is None else nrhs
         self._chk(self.lib.gpk_trsm(self.h, int(trans), L.ptr, n, L.ld, B.ptr, nrhs, B.ld))
 
-    def trtri_diag(self, L, n=None):
-        """inverses of the 256 x 256 diagonal blocks of the factor L -> (n, 256) device array (gpk_trtri_diag)"""
+    def trtri_diag(self, L, n=None, block=None):
+        """inverses of the block x block diagonal blocks of the factor L -> (n, block) device array (gpk_trtri_diag)"""
         n = L.rows if n is None else n
-        D = DeviceArray(self, n, 256, ld=256)
-        self._chk(self.lib.gpk_trtri_diag(self.h, L.ptr, n, L.ld, D.ptr))
+        block = DINV_BLOCK if block is None else int(block)
+        D = DeviceArray(self, n, block, ld=block)
+        self._chk(self.lib.gpk_trtri_diag(self.h, L.ptr, n, L.ld, D.ptr, block))
         return D
 
     def trsm_dinv(self, L, Dinv, B, X, n=None, nrhs=None, lead=0):
         """X <- L^{-1} B through the inverted diagonal blocks (B becomes scratch; X zero on entry when lead > 0)"""
         n = L.rows if n is None else n
         nrhs = B.cols if nrhs is None else nrhs
-        self._chk(self.lib.gpk_trsm_dinv(self.h, L.ptr, Dinv.ptr, n, L.ld, B.ptr, nrhs, B.ld, X.ptr, X.ld, int(lead)))
+        self._chk(self.lib.gpk_trsm_dinv(self.h, L.ptr, Dinv.ptr, Dinv.ld, n, L.ld, B.ptr, nrhs, B.ld, X.ptr, X.ld, int(lead)))
 
     def potrs(self, L, B, n=None, nrhs=None):
         n = L.rows if n is None else n

@@ -189,8 +189,9 @@ def test_trsm(ctx, trans, n, nrhs):
 
 @pytest.mark.parametrize('n,nrhs,lead', [(64, 64, 0), (256, 100, 0), (300, 77, 0), (1000, 257, 0), (1537, 1001, 0), (2360, 1101, 1100),
                                          (1924, 901, 900), (700, 650, 649), (513, 300, 200)])
-def test_trsm_dinv(ctx, n, nrhs, lead):
-    """All-GEMM forward solve through the explicit inverses of the 256-wide diagonal blocks (gpk_trtri_diag + gpk_trsm_dinv)
+@pytest.mark.parametrize('block', [256, 512, 1024])
+def test_trsm_dinv(ctx, n, nrhs, lead, block):
+    """All-GEMM forward solve through the explicit inverses of the diagonal blocks (256, 512 or 1024 rows; gpk_trtri_diag + gpk_trsm_dinv)
     against numpy and against the substitution path; lead > 0: right-hand sides with the leading-zero shape of [A | F]."""
     rng = np.random.RandomState(n + nrhs)
     L = np.tril(rng.normal(size=(n, n))) + np.diag(rng.uniform(3, 4, n) * np.sqrt(n))
@@ -199,10 +200,10 @@ def test_trsm_dinv(ctx, n, nrhs, lead):
         rows = np.arange(n)[:, None]; cols = np.arange(nrhs)[None, :]
         B[(cols < lead) & (rows < lead - 1 - cols)] = 0.0
     dL = ctx.array(L)
-    D = ctx.trtri_diag(dL)
+    D = ctx.trtri_diag(dL, block=block)
     Dh = D.download()
-    for k0 in range(0, n, 256):                                   # each block: inverse of the diagonal block, exact zeros above
-        nk = min(256, n - k0)
+    for k0 in range(0, n, block):                                 # each block: inverse of the diagonal block, exact zeros above
+        nk = min(block, n - k0)
         blk = Dh[k0:k0 + nk, :nk]
         assert np.all(np.triu(blk, 1) == 0.0)
         assert np.linalg.norm(L[k0:k0 + nk, k0:k0 + nk] @ blk - np.eye(nk)) <= 1e-12 * nk
