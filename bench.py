@@ -154,6 +154,20 @@ class AbortWatch:
         self.thread.join(timeout=5)
 
 
+def syrk_pipelined_flops(N, nz, tile=64, bk=16, ob=512):
+    """Flops LAUNCHED for Hb = S^T S in the pipelined form (csrc/gpk_factor.hip, gpk_i_syrk_potrf): one product per
+    512-column block over the rows from the block's first row down; tiles entirely above the diagonal are skipped, so this
+    equals the lower-tile count of the single-launch form."""
+    nc = nz + 1
+    total = 0.0
+    for j0 in range(0, nc, ob):
+        for n0 in range(j0, min(j0 + ob, nc), tile):
+            bn = min(tile, nc - n0)
+            k0 = (max(0, nz - (n0 + tile)) // bk) * bk
+            total += 2.0 * bn * (nc - n0) * (N - k0)              # tile rows from the diagonal tile down
+    return total
+
+
 # ------------------------------------------------------------------------------------------------------ single GPU
 def run_single(args, workload, comm=None):
     """One independent solve on this rank's GPU.  With `comm` (N > 1 ranks): the timed region is bracketed by barriers and
@@ -221,8 +235,15 @@ def run_single(args, workload, comm=None):
     test_l2 = float(np.sqrt(np.sum((u_true(Xt[:, 0], Xt[:, 1]) - ext) ** 2) / Xt.shape[0]))
 
     steps = max(prof['steps'], 1)
-    syrk_ms = prof['syrk_ms'] / steps
-    syrk_flops = syrk_executed_flops(N, nz)                      # what the launch executes (leading zeros skipped)
+    # the SYRK launch(es) Hb = S^T S, timed by HIP events on the stream they run on, inside the timed steps.  Pipelined mode
+    # (default): the product is issued as one launch per 512-column block on the GEMM partition (256 - chain_cus CUs) while the
+    # panel chains of the factorisation run on the other CUs; syrk_ms is the SUM of those launches per step.
+    syrk_ms = prof['syrk_launch_ms'] / steps
+    phase_ms = prof['syrk_ms'] / steps                            # product + factorisation of Hb (one phase since round 2)
+    pipelined = prof['pipelined']
+    gemm_cus = 256 - prof['chain_cus'] if pipelined else 256
+    syrk_flops = syrk_executed_flops(N, nz)                      # lower tiles, leading zeros skipped (the useful work)
+    syrk_launched = syrk_pipelined_flops(N, nz) if pipelined else syrk_flops
     syrk_dense = float(N) * (nz + 1) ** 2                        # dense symmetric count, SURVEY 8d ("SYRK N n_z^2")
     achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12
     traffic, traffic_source = stored_pmc_traffic()
@@ -242,13 +263,20 @@ def run_single(args, workload, comm=None):
         'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': args.warmup + args.steps,
                      'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
         'f1_tflops': world * f1_flops(N, nz) * args.steps / elapsed / 1e12,
-        'phases_ms_per_step': {'trsm': prof['trsm_ms'] / steps, 'syrk': syrk_ms, 'potrf_H': prof['potrf_ms'] / steps,
-                               'trsv_update': prof['trsv_update_ms'] / steps},
+        'phases_ms_per_step': {'trsm': prof['trsm_ms'] / steps, 'syrk_and_potrf_H': phase_ms,
+                               'syrk_launches_sum': syrk_ms, 'trsv_update': prof['trsv_update_ms'] / steps,
+                               'pipelined': bool(pipelined), 'chain_partition_cus': prof['chain_cus'] if pipelined else 0},
         'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms},
         'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<TN, lower tiles> = SYRK Hb = S^T S',
                      'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
                      'traffic': traffic, 'traffic_source': traffic_source, 'flops_per_launch': syrk_flops, 'dense_flops_per_launch': syrk_dense,
                      'dense_equivalent_tflops': syrk_dense / (syrk_ms * 1e-3) / 1e12, 'avg_launch_ms': syrk_ms,
+                     'launches_per_step': (nz + 1 + 511) // 512 if pipelined else 1, 'cus_available_to_kernel': gemm_cus,
+                     'frac_of_partition_peak': achieved / (FP64_MFMA_PEAK_TFLOPS * gemm_cus / 256.0),
+                     'launched_flops_per_step': syrk_launched,
+                     'note': 'flops_per_launch = useful flops of the product per step (lower tiles, structural zeros skipped); avg_launch_ms = '
+                             'sum of the product launches per step; peak is the FULL chip although the launches only get '
+                             'cus_available_to_kernel CUs when pipelined (the rest runs the Cholesky panel chain concurrently)',
                      'peak_source': 'datasheet fp64 matrix rate; v_mfma_f64_16x16x4_f64 issue-rate ubench on this chip ~74'},
         'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble_kernel<elliptic>', 'achieved': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -60,6 +60,11 @@ int gpk_timer_stop(gpk_handle h, double* host_ms);            /* synchronises */
  * host_ms4 = accumulated milliseconds of {TRSM phase, the SYRK launch, POTRF of H, TRSV + update} over *host_count steps. */
 int gpk_prof_enable(gpk_handle h, int on);                    /* also resets the accumulators */
 int gpk_prof_read(gpk_handle h, double* host_ms4, int* host_count);
+/* gpk_gn_step forms Hb = S^T S and factors it in one pipelined phase (product by 512-column blocks on a GEMM stream, panel
+ * chains on a second stream with a disjoint CU mask): host_ms4[1] is then the wall time of that whole phase and host_ms4[2]
+ * is 0.  *host_pipelined = 1 if the last step ran pipelined; *host_syrk_launch_ms = accumulated duration of the SYRK launches
+ * themselves (HIP events on the stream they ran on); *host_chain_cus = CUs of the chain partition. */
+int gpk_prof_read_pipeline(gpk_handle h, int* host_pipelined, double* host_syrk_launch_ms, int* host_chain_cus);
 
 /* ---- Gram assembly: replaces Gram_matrix_assembly (src/Gram_matrice.py:11-187) plus the nugget of
  *      *.Gram_matrix (src/PDEs.py:56-73,250-269,391-409; src/InverseProblems.py:66-99) in one fused pass.
@@ -167,7 +172,9 @@ int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* host_prob, const dou
 int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* out);
 
 /* development aids (process-wide): key 0 = force the GEMM tile configuration (0 auto, 1 = 128x128, 2 = 64x64);
- * key 2 = run multi-RHS triangular solves as 4 column groups on concurrent streams (0 off, default) */
+ * key 2 = run multi-RHS triangular solves as 4 column groups on concurrent streams (0 off, default); key 10 = 0: substitution
+ * strips even when Dinv is given; key 12 = 0: SYRK then right-looking Cholesky on one stream instead of the two-partition
+ * pipeline; key 13 = CUs of the chain partition (default 64); the full list is in tools/README.md */
 int gpk_debug_set(int key, int value);
 /* development aid: enable/disable and read the shader-clock phase stamps of the 64-wide diagonal-block kernels */
 int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable);
@@ -177,6 +184,9 @@ int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops);      /* v
 int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, double* host_gbps);
 int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_per_op);
 int gpk_ubench_xcc_map(gpk_handle h, int nblocks, int mode, int* host_out);   /* XCD id (HW_REG_XCC_ID) each workgroup ran on; mode 1: odd workgroups linger */   /* 0 dep. v_fma_f64, 1 indep. v_fma_f64, 2 dep. ds_read, 3 indep. ds_read, 4 dep. mfma_f64 (shader cycles per op, one wave) */
+/* which CUs a stream created with hipExtStreamCreateWithCUMask(bits [first_bit, first_bit + nbits)) dispatches to: per
+ * workgroup XCC_ID | HW_REG_HW_ID << 8 (tools/cu_mask_probe.py) */
+int gpk_ubench_cu_census(gpk_handle h, int first_bit, int nbits, int nblocks, int* host_out);
 /* development probe (tools/overlap_probe.py): C2 <- S^T S on a low-priority side stream while potrf(copy of H) runs on the
  * handle's stream; host_ms3 = {potrf alone, syrk alone, both concurrently}.  Round-1 finding: no overlap (5.5 vs 2.9 + 2.5 ms). */
 int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,

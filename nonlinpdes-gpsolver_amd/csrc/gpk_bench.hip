@@ -140,6 +140,33 @@ extern "C" int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_pe
     return 0;
 }
 
+// census of the CUs a CU-masked stream dispatches to: every workgroup lingers ~20 us (so that the grid spreads over all enabled
+// CUs) and reports XCC_ID | HW_ID << 8 (HW_REG_HW_ID: CU_ID bits 11:8, SH_ID 12, SE_ID 15:13 on gfx9)
+__global__ void cu_census_kernel(int* out) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;
+    const int hwid = __builtin_amdgcn_s_getreg((15 << 11) | 4) & 0xffff;
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc | (hwid << 8);
+    const long t0 = clock64();
+    while (clock64() - t0 < 40000) {}
+}
+
+extern "C" int gpk_ubench_cu_census(gpk_handle h, int first_bit, int nbits, int nblocks, int* host_out) {
+    if (!h || !host_out || nblocks <= 0 || first_bit < 0 || nbits <= 0 || first_bit + nbits > 256) return GPK_ERR_ARG;
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = first_bit; i < first_bit + nbits; ++i) mask[i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    GPK_HIP(h, hipExtStreamCreateWithCUMask(&s, 8, mask));
+    int* d = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&d, nblocks * sizeof(int)));
+    cu_census_kernel<<<nblocks, 256, 0, s>>>(d);
+    GPK_LAUNCH_CHECK(h);
+    GPK_HIP(h, hipMemcpyAsync(host_out, d, nblocks * sizeof(int), hipMemcpyDeviceToHost, s));
+    GPK_HIP(h, hipStreamSynchronize(s));
+    GPK_HIP(h, hipFree(d));
+    GPK_HIP(h, hipStreamDestroy(s));
+    return 0;
+}
+
 extern "C" int gpk_ubench_xcc_map(gpk_handle h, int nblocks, int mode, int* host_out) {
     if (!h || !host_out || nblocks <= 0) return GPK_ERR_ARG;
     int* d = nullptr;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 #include "../../include/gpk.h"
 
 #define GPK_ERR_ARG (-9001)
@@ -28,6 +29,15 @@ struct gpk_ctx {
     size_t work_cap = 0;            // bytes
     long work_sig[5] = {0, 0, 0, 0, 0};   // (rows, ld, nrhs, lead, system) of the last solve into d_work: its never-written
                                     // zero region is still valid when the next solve has the same shape
+    // SYRK/Cholesky pipeline of the Gauss-Newton step (gpk_i_syrk_potrf): two streams with disjoint CU masks -- the GEMM stream
+    // and the "chain" stream that runs the latency-bound panel kernels -- and the events that order them
+    hipStream_t pipe_g = nullptr, pipe_c = nullptr;
+    int pipe_chain_cus = 0;
+    std::vector<hipEvent_t> pipe_ev;        // ordering events (timing disabled)
+    std::vector<hipEvent_t> pipe_tev;       // timing events around the SYRK launches (only while prof is on)
+    int pipe_tev_used = 0;
+    double prof_syrk_ms = 0;                // accumulated duration of the SYRK launches on the GEMM stream (pipelined mode)
+    int prof_pipelined = 0;
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
@@ -59,8 +69,14 @@ int gpk_bad_arg(gpk_handle h, const char* what);
 // ---- internal (stream-ordered, no host sync) building blocks -------------------------------------------------
 // C <- alpha*op(A)*op(B) + beta*C.  lower_only: skip tiles strictly above the diagonal (square C).
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
-               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0, bool tri_a = false);
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0, bool tri_a = false,
+               bool skip_upper = false);
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
+int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base);
+// Hb <- chol(W^T W) (lower, nc x nc; W is rows x nc with the leading-zero shape `lead` of gpk_i_gemm), the product and the
+// factorisation pipelined by 512-column blocks on two CU partitions (gpk_factor.hip); d_loss (device, may be null) receives
+// the unfactored last diagonal entry (W^T W)[nc-1][nc-1]
+int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss);
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb);
 // forward solve exploiting leading zeros of the right-hand side columns (see gpk_factor.hip)
 int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead, int row0);

@@ -54,6 +54,10 @@ extern "C" int gpk_destroy(gpk_handle h) {
     if (h->d_obflags) (void)hipFree(h->d_obflags);
     if (h->d_pts) (void)hipFree(h->d_pts);
     if (h->d_work) (void)hipFree(h->d_work);
+    for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->pipe_tev) (void)hipEventDestroy(e);
+    if (h->pipe_g) (void)hipStreamDestroy(h->pipe_g);
+    if (h->pipe_c) (void)hipStreamDestroy(h->pipe_c);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (int i = 0; i < 3; ++i) {
@@ -173,6 +177,16 @@ extern "C" int gpk_prof_enable(gpk_handle h, int on) {
     h->prof = on != 0;
     for (int i = 0; i < 4; ++i) h->prof_ms[i] = 0.0;
     h->prof_cnt = 0;
+    h->prof_syrk_ms = 0.0;
+    h->prof_pipelined = 0;
+    return 0;
+}
+
+extern "C" int gpk_prof_read_pipeline(gpk_handle h, int* host_pipelined, double* host_syrk_launch_ms, int* host_chain_cus) {
+    if (!h) return GPK_ERR_ARG;
+    if (host_pipelined) *host_pipelined = h->prof_pipelined;
+    if (host_syrk_launch_ms) *host_syrk_launch_ms = h->prof_syrk_ms;
+    if (host_chain_cus) *host_chain_cus = h->pipe_chain_cus;
     return 0;
 }
 

@@ -1223,6 +1223,125 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     return 0;
 }
 
+// ---- SYRK + Cholesky of the Gauss-Newton matrix, pipelined on two CU partitions -------------------------------------------
+// Hb = W^T W followed by chol(Hb) is 1.6 ms of GEMM followed by a 2.5 ms phase that is mostly a latency chain (63 panel
+// kernels of ~25 us that keep <= 63 workgroups busy, plus their rank-64 updates).  Running the two on plain concurrent
+// streams does not overlap them: the GEMM's workgroups fill every CU, and a panel workgroup that does squeeze in next to
+// GEMM waves runs 3-8x slower (measured, tools/overlap_probe.py: issue arbitration, LDS and the matrix pipe are shared; a
+// raised s_setprio does not help).  What works is a SPATIAL partition: hipExtStreamCreateWithCUMask gives the chain stream c
+// CUs (bit i of the mask is a CU of XCD i mod 8 -- tools/cu_mask_probe.py -- so a multiple of 8 takes c/8 CUs from every
+// XCD) and the GEMM stream the other 256 - c, and the factorisation is reordered LEFT-looking over 512-column blocks so that
+// it can start before the product is complete:
+//     GEMM stream, block j:  S_j: Hb[j0:, j0:j0+512] = W[:, j0:]^T W[:, j0:j0+512]          (all rows below, leading zeros skipped)
+//                            U_j: Hb[j0:, j0:j0+512] -= L[j0:, 0:j0] L[j0:j0+512, 0:j0]^T   (panels 0..j-2 first, then -- once the
+//                                 chain stream has finished block j-1 -- the last 512 columns)
+//     chain stream, block j: wait for U_j; gpk_i_potrf_panel (64-column panel kernels + rank-64 updates inside the block)
+// The chain of block j runs next to S_{j+1} and the early part of U_{j+1}.  Same flops as the right-looking order (plus the
+// upper triangles of the 512 x 512 diagonal blocks, which are computed and never read).
+int g_pipeline = 1;                                                  // gpk_debug_set key 12: 0 = SYRK, then right-looking Cholesky, on one stream
+int g_pipeline_chain_cus = 64;                                       // gpk_debug_set key 13: CUs of the chain partition (multiple of 8)
+
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
+    int c = (g_pipeline_chain_cus / 8) * 8;
+    if (c < 8) c = 8;
+    if (c > h->num_cu - 8) c = h->num_cu - 8;
+    if (!h->pipe_g || h->pipe_chain_cus != c) {
+        if (h->pipe_g) { GPK_HIP(h, hipStreamSynchronize(h->pipe_g)); GPK_HIP(h, hipStreamDestroy(h->pipe_g)); h->pipe_g = nullptr; }
+        if (h->pipe_c) { GPK_HIP(h, hipStreamSynchronize(h->pipe_c)); GPK_HIP(h, hipStreamDestroy(h->pipe_c)); h->pipe_c = nullptr; }
+        uint32_t mc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < h->num_cu && i < 256; ++i) ((i < c) ? mc : mg)[i >> 5] |= 1u << (i & 31);
+        GPK_HIP(h, hipExtStreamCreateWithCUMask(&h->pipe_c, 8, mc));
+        GPK_HIP(h, hipExtStreamCreateWithCUMask(&h->pipe_g, 8, mg));
+        h->pipe_chain_cus = c;
+    }
+    while (h->pipe_ev.size() < nev) {
+        hipEvent_t e;
+        GPK_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->pipe_ev.push_back(e);
+    }
+    while (h->pipe_tev.size() < ntev) {
+        hipEvent_t e;
+        GPK_HIP(h, hipEventCreate(&e));
+        h->pipe_tev.push_back(e);
+    }
+    return 0;
+}
+
+int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss) {
+    constexpr int OB = 512;
+    const int J = gpk_ceil_div(nc, OB);
+    h->pipe_tev_used = 0;
+    if (!g_pipeline || J < 3 || h->num_cu < 64) {                    // small systems: nothing to overlap
+        if (h->prof) {
+            while (h->pipe_tev.size() < 2) { hipEvent_t e; GPK_HIP(h, hipEventCreate(&e)); h->pipe_tev.push_back(e); }
+            GPK_HIP(h, hipEventRecord(h->pipe_tev[0], h->stream));
+        }
+        GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, rows, 1.0, W, ldw, W, ldw, 0.0, Hb, ldh, true, lead));
+        if (h->prof) { GPK_HIP(h, hipEventRecord(h->pipe_tev[1], h->stream)); h->pipe_tev_used = 2; }
+        if (d_loss) GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)(nc - 1) * ldh + (nc - 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        return gpk_i_potrf(h, Hb, nc, ldh, 0);
+    }
+    GPK_TRY(pipe_setup(h, 2 * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
+    const hipStream_t main_s = h->stream, G = h->pipe_g, C = h->pipe_c;
+    auto product = [&](int j) {                                      // S_j (tiles above the diagonal of the block are skipped)
+        const int j0 = j * OB, ob = (nc - j0 < OB) ? nc - j0 : OB, m = nc - j0;
+        return gpk_i_gemm(h, true, false, m, ob, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
+                          lead > j0 ? lead - j0 : 0, false, true);
+    };
+    hipEvent_t* ev_ready = h->pipe_ev.data();                        // [J]
+    hipEvent_t* ev_chain = h->pipe_ev.data() + J;                    // [J]
+    hipEvent_t ev_fork = h->pipe_ev[2 * J];
+    int rc = 0;
+    auto fail = [&](hipError_t e, const char* what) { h->stream = main_s; return gpk_fail(h, e, what, __FILE__, __LINE__); };
+#define PIPE_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
+    // block 0 has nothing to overlap with: its product runs on the whole chip, before the fork
+    if (h->prof) PIPE_HIP(hipEventRecord(h->pipe_tev[0], main_s));
+    rc = product(0);
+    if (rc) return rc;
+    if (h->prof) { PIPE_HIP(hipEventRecord(h->pipe_tev[1], main_s)); h->pipe_tev_used = 2; }
+    PIPE_HIP(hipEventRecord(ev_fork, main_s));
+    PIPE_HIP(hipStreamWaitEvent(G, ev_fork, 0));
+    PIPE_HIP(hipStreamWaitEvent(C, ev_fork, 0));
+    for (int j = 0; j < J && rc == 0; ++j) {
+        const int j0 = j * OB, ob = (nc - j0 < OB) ? nc - j0 : OB, m = nc - j0;
+        double* Hjj = Hb + (long)j0 * ldh + j0;
+        h->stream = G;
+        if (j > 0) {
+            if (h->prof) PIPE_HIP(hipEventRecord(h->pipe_tev[2 * j], G));
+            rc = product(j);
+            if (h->prof) { PIPE_HIP(hipEventRecord(h->pipe_tev[2 * j + 1], G)); h->pipe_tev_used = 2 * (j + 1); }
+            if (rc) break;
+        }
+        if (j == J - 1 && d_loss)
+            PIPE_HIP(hipMemcpyAsync(d_loss, Hb + (long)(nc - 1) * ldh + (nc - 1), sizeof(double), hipMemcpyDeviceToDevice, G));
+        if (j > 0) {
+            const double* Lrow = Hb + (long)j0 * ldh;                // rows j0.. of the factored panels, columns 0..j0
+            if (j > 1) {                                             // panels 0..j-2: their chain finished an iteration ago
+                rc = gpk_i_gemm(h, false, true, m, ob, (j - 1) * OB, -1.0, Lrow, ldh, Lrow, ldh, 1.0, Hjj, ldh, false, 0, false, true);
+                if (rc) break;
+            }
+            PIPE_HIP(hipStreamWaitEvent(G, ev_chain[j - 1], 0));
+            rc = gpk_i_gemm(h, false, true, m, ob, OB, -1.0, Lrow + (j - 1) * OB, ldh, Lrow + (j - 1) * OB, ldh, 1.0, Hjj, ldh, false, 0, false, true);
+            if (rc) break;
+        }
+        PIPE_HIP(hipEventRecord(ev_ready[j], G));
+        h->stream = C;
+        PIPE_HIP(hipStreamWaitEvent(C, ev_ready[j], 0));
+        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, j0);
+        if (rc) break;
+        PIPE_HIP(hipEventRecord(ev_chain[j], C));
+    }
+    h->stream = main_s;
+    if (rc) {                                                        // drain both side streams before reporting
+        (void)hipStreamSynchronize(G); (void)hipStreamSynchronize(C);
+        return rc;
+    }
+    PIPE_HIP(hipStreamWaitEvent(main_s, ev_chain[J - 1], 0));       // (everything on G precedes ev_ready[J-1], which C waited for)
+#undef PIPE_HIP
+    h->prof_pipelined = 1;
+    return 0;
+}
+
 int g_probe_chain_cus = 0;                                           // gpk_debug_set key 11: overlap probe with a CU-mask partition
 int g_fused_trsv = 1;                                                 // gpk_debug_set key 4: 0 = two launches per block
 
@@ -1272,6 +1391,8 @@ extern "C" int gpk_debug_set_fused_trsv(int v) { g_fused_trsv = v; return 0; }
 extern "C" int gpk_debug_set_fused_panel(int v) { g_fused_panel = v; return 0; }
 extern "C" int gpk_debug_set_persistent_ob(int v) { g_persistent_ob = v; return 0; }
 extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; return 0; }
+extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

@@ -41,6 +41,8 @@ struct GemmArgs {
     int lead;          // operand B (stored [k][n]) has column n zero for k < lead-1-n: the tile with columns [n0, n0+BN)
                        // gets no contribution from k < lead - (n0 + BN), so its K loop starts there.  (SYRK S^T S,
                        // lower tiles: the A tile's columns are further right, i.e. non-zero even earlier.)
+    int skip_upper;    // C is a block column whose top square is a diagonal block of a symmetric matrix: tiles entirely above
+                       // that diagonal (m0 + BM <= n0) are not computed (their content is never read)
     int tri_a;         // operand A (TA = false, stored [m][k]) is lower triangular: row m has no entries at k > m, so the tile
                        // with rows [m0, m0+BM) stops its K loop at m0+BM (the explicit inverses of diagonal blocks, gpk_trsm_dinv)
     int vecA, vecB;
@@ -197,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // 30-50 VGPRs and a wave of occupancy)
     auto tile = [&](const int tm) __attribute__((always_inline)) {
     const int m0 = tm * BM;
+    if (g.skip_upper && m0 + BM <= n0) return;
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -494,6 +497,8 @@ extern "C" int gpk_debug_set_fused_panel(int v);
 extern "C" int gpk_debug_set_persistent_ob(int v);
 extern "C" int gpk_debug_set_use_dinv(int v);
 extern "C" int gpk_debug_set_probe_chain_cus(int v);
+extern "C" int gpk_debug_set_pipeline(int v);
+extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -507,11 +512,13 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 6) { g_supertile = value; return 0; }
     if (key == 10) return gpk_debug_set_use_dinv(value);
     if (key == 11) return gpk_debug_set_probe_chain_cus(value);
+    if (key == 12) return gpk_debug_set_pipeline(value);
+    if (key == 13) return gpk_debug_set_pipeline_chain_cus(value);
     return GPK_ERR_ARG;
 }
 
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
-               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead, bool tri_a) {
+               const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead, bool tri_a, bool skip_upper) {
     if (m <= 0 || n <= 0) return 0;
     if (k < 0 || !A || !B || !C) return gpk_bad_arg(h, "gemm: sizes/pointers");
     if (lower_only && m != n) return gpk_bad_arg(h, "gemm: lower_only needs a square C");
@@ -521,9 +528,10 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.lower_only = lower_only ? 1 : 0;
     g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
+    g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
-    if (k <= 64 && !lower_only && !g.tri_a && g_force_cfg == 0 &&
+    if (k <= 64 && !lower_only && !g.tri_a && !g.skip_upper && g_force_cfg == 0 &&
         (beta == 0.0 || (beta == 1.0 && (alpha == 1.0 || alpha == -1.0))))
         return launch_k64(h, ta, tb, g);
     // The 64x64 configuration (4 workgroups per CU, two slabs in flight) is used for every shape: with the straight-line
@@ -536,6 +544,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // only 1-2 workgroups per CU, i.e. one wave per SIMD and nothing to hide latency behind; 32x64 tiles double that
     long t64 = (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64);
     if (g.tri_a) t64 /= 2;                                            // workgroups handle pairs of row tiles
+    // (also for long K: restricting this to K <= 1024 was measured slower on the 512-column products of the pipelined SYRK and on
+    // the mid-size updates of the triangular solve -- 504 tiles of 64x64 leave the CUs at 2-3 workgroups)
     if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
     return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
 }

@@ -181,7 +181,7 @@ int g_use_dinv = 1;                  // gpk_debug_set key 10: 0 = substitution s
 // With the inverses of the diagonal blocks of every factor at hand (gpk_trtri_diag, gpk_gn_problem::Dinv) the solve runs
 // out of place into the handle's workspace W (all-GEMM, see gpk_i_trsm_left_dinv) and the SYRK reads W; S is scratch then.
 int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, double* S, int lds,
-                              double* Hb, int ldh, double alpha, int rev) {
+                              double* Hb, int ldh, double alpha, int rev, double** Wout = nullptr) {
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
     bool dinv = g_use_dinv != 0;
@@ -218,6 +218,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
         }
     }
     GPK_PROF_MARK(h, 1);
+    if (Wout) { *Wout = W; return 0; }                               // gn_step: product and factorisation are pipelined by the caller
     GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, W, lds, W, lds, 0.0, Hb, ldh, true, rev ? d.nz : 0));
     GPK_PROF_MARK(h, 2);
     return 0;
@@ -240,11 +241,14 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     GPK_TRY(check_prob(h, p, d));
     const int nz = d.nz;
     const int rev = (p->system == GPK_GN_ELLIPTIC) ? 1 : 0;
-    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev));
+    double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
+    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     double* d_loss = h->d_scalars;
-    GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
-    GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));                     // last row of the factor = (L_H^{-1} g/2)^T
+    // Hb = W^T W and its Cholesky factor, pipelined by column blocks (gpk_factor.hip); d_loss = Hb[nz][nz] before factoring;
+    // the last row of the factor is (L_H^{-1} g/2)^T
+    GPK_TRY(gpk_i_syrk_potrf(h, W, lds, d.rows, nz + 1, rev ? nz : 0, Hb, ldh, d_loss));
+    GPK_PROF_MARK(h, 2);
     GPK_PROF_MARK(h, 3);
     double* dl = rev ? S : delta;                                    // scratch for the (reversed-order) solution: S is free now
     GPK_HIP(h, hipMemcpyAsync(dl, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -269,6 +273,11 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
             h->prof_ms[i] += (double)ms;
         }
         h->prof_cnt += 1;
+        for (int i = 0; i + 1 < h->pipe_tev_used; i += 2) {          // SYRK launches of the pipelined product (GEMM stream)
+            float ms = 0.f;
+            GPK_HIP(h, hipEventElapsedTime(&ms, h->pipe_tev[i], h->pipe_tev[i + 1]));
+            h->prof_syrk_ms += (double)ms;
+        }
     }
     if (info == nz + 1) info = 0;          // the border pivot loss - y^T y is not part of H (may round below zero)
     if (host_info) *host_info = info;

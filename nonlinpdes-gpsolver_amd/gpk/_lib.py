@@ -44,6 +44,7 @@ PROTOTYPES = {
     'gpk_timer_stop': (_i, [_vp, _pd]),
     'gpk_prof_enable': (_i, [_vp, _i]),
     'gpk_prof_read': (_i, [_vp, _pd, _pi]),
+    'gpk_prof_read_pipeline': (_i, [_vp, _pi, _pd, _pi]),
     'gpk_assemble': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _d, _i, _vp, _i, _pd]),
     'gpk_assemble_test': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _i]),
     'gpk_extend': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
@@ -74,6 +75,7 @@ PROTOTYPES = {
     'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
     'gpk_ubench_latency': (_i, [_vp, _i, _pd]),
     'gpk_ubench_xcc_map': (_i, [_vp, _i, _i, _pi]),
+    'gpk_ubench_cu_census': (_i, [_vp, _i, _i, _i, _pi]),
     'gpk_debug_overlap_probe': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _pd]),
 }
 

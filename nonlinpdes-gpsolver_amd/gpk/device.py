@@ -319,7 +319,12 @@ class Context:
         ms = (C.c_double * 4)()
         n = C.c_int()
         self._chk(self.lib.gpk_prof_read(self.h, ms, C.byref(n)))
-        return dict(steps=n.value, trsm_ms=ms[0], syrk_ms=ms[1], potrf_ms=ms[2], trsv_update_ms=ms[3])
+        pipelined, cus, syrk_launch = C.c_int(), C.c_int(), C.c_double()
+        self._chk(self.lib.gpk_prof_read_pipeline(self.h, C.byref(pipelined), C.byref(syrk_launch), C.byref(cus)))
+        # pipelined: syrk_ms is the wall time of the fused product + factorisation phase and potrf_ms is 0;
+        # syrk_launch_ms = the SYRK launches themselves (events on the stream they ran on)
+        return dict(steps=n.value, trsm_ms=ms[0], syrk_ms=ms[1], potrf_ms=ms[2], trsv_update_ms=ms[3],
+                    pipelined=bool(pipelined.value), syrk_launch_ms=syrk_launch.value, chain_cus=cus.value)
 
     # ---- micro-benchmarks ----
     def ubench_mfma_f64(self, iters=20000):
