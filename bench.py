@@ -93,6 +93,55 @@ def syrk_executed_flops(N, nz, tile=64, bk=16):
     return total
 
 
+def trsm_dinv_executed_flops(N, nz, db=1024, num_cu=256, nb=64, bk=16):
+    """(flops, launches) executed by the solve phase S = L^{-1}[A | F] of one step (gpk_i_trsm_left_dinv with lead = n_z, nrhs =
+    n_z + 1) -- mirrors csrc/gpk_factor.hip / gpk_gemm.hip: recursion split at multiples of the inverted-block size db, active
+    column range rounded down to 64, per 64-wide column tile the K loop starts at floor(max(0, lz - (n0 + 64)) / 16) * 16, the
+    triangular leaf products stop at each row tile's last row.  All of it is ONE kernel, gemm_f64_kernel<.., NN>."""
+    nrhs, lead = nz + 1, nz
+    acc = [0.0, 0]
+
+    def gemm(m, n, k, lz, tri):
+        if m <= 0 or n <= 0:
+            return
+        acc[1] += 1
+        t64 = ((m + 63) // 64) * ((n + 63) // 64)
+        if tri:
+            t64 //= 2
+        bm = 32 if (t64 < 2 * num_cu and m >= 64) else 64
+        for n0 in range(0, n, 64):
+            bn = min(64, n - n0)
+            k0 = (max(0, lz - (n0 + 64)) // bk) * bk if lz > 0 else 0
+            if tri:
+                for m0 in range(0, m, bm):
+                    acc[0] += 2.0 * min(bm, m - m0) * bn * max(0, min(k, m0 + bm) - k0)
+            else:
+                acc[0] += 2.0 * m * bn * max(0, k - min(k0, k))
+
+    def rec(n, row0):
+        if n <= 0:
+            return
+        clo = lead - (row0 + n)
+        clo = (clo // nb) * nb if clo > 0 else 0
+        if clo >= nrhs:
+            return
+        if n <= db:
+            gemm(n, nrhs - clo, n, max(lead - row0 - clo, 0), True)
+            return
+        n1 = ((n // 2 + db - 1) // db) * db
+        if n1 >= n:
+            n1 = db
+        rec(n1, row0)
+        c1 = lead - (row0 + n1)
+        c1 = (c1 // nb) * nb if c1 > 0 else 0
+        if c1 < nrhs:
+            gemm(n - n1, nrhs - c1, n1, max(lead - row0 - c1, 0), False)
+        rec(n - n1, row0 + n1)
+
+    rec(N, 0)
+    return acc[0], acc[1]
+
+
 def stored_pmc_traffic():
     """`roofline.traffic` cannot be measured inside this process (PMC counters need a rocprofv3 --pmc pass of their own,
     tools/profile_round.sh): it is READ from the newest committed profiles/rNN_pmc_syrk.json and labelled as such."""
@@ -247,6 +296,11 @@ def run_single(args, workload, comm=None):
     syrk_dense = float(N) * (nz + 1) ** 2                        # dense symmetric count, SURVEY 8d ("SYRK N n_z^2")
     achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12
     traffic, traffic_source = stored_pmc_traffic()
+    # dominant kernel of the step: gemm_f64_kernel<NN> = the whole solve phase S = L^{-1}[A | F] (GEMMs only since round 2)
+    trsm_ms = prof['trsm_ms'] / steps
+    uses_dinv = prob.Dinv is not None and os.environ.get('GPK_DEBUG_SET', '').find('10=0') < 0
+    trsm_flops, trsm_launches = trsm_dinv_executed_flops(N, nz, gpk.device.DINV_BLOCK) if uses_dinv else (None, None)
+    trsm_achieved = trsm_flops / (trsm_ms * 1e-3) / 1e12 if trsm_flops else None
     out = {
         'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
         'value': world * args.steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -267,7 +321,21 @@ def run_single(args, workload, comm=None):
                                'syrk_launches_sum': syrk_ms, 'trsv_update': prof['trsv_update_ms'] / steps,
                                'pipelined': bool(pipelined), 'chain_partition_cus': prof['chain_cus'] if pipelined else 0},
         'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms},
-        'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<TN, lower tiles> = SYRK Hb = S^T S',
+        'roofline': ({'bound': 'mfma',
+                      'kernel': 'gemm_f64_kernel<.., NN> = the solve phase S = L^{-1}[A | F]: update products of the recursion and '
+                                'triangular products with the inverted diagonal blocks of the factor, all fp64 MFMA',
+                      'achieved': trsm_achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': trsm_achieved / FP64_MFMA_PEAK_TFLOPS,
+                      'traffic': None, 'traffic_source': 'not collected for this kernel family (PMC pass of the SYRK kernel: roofline_syrk)',
+                      'flops_per_step': trsm_flops, 'launches_per_step': trsm_launches, 'phase_ms_per_step': trsm_ms,
+                      'avg_launch_ms': trsm_ms / trsm_launches,
+                      'dense_flops_per_step': float(N) * N * (nz + 1), 'dense_equivalent_tflops': float(N) * N * (nz + 1) / (trsm_ms * 1e-3) / 1e12,
+                      'peak_source': 'datasheet fp64 matrix rate (2.4 GHz); v_mfma_f64_16x16x4_f64 issue-rate ubench on this chip 71-74 '
+                                     '(the chip sustains ~2.1-2.2 GHz under fp64 MFMA load)',
+                      'note': 'achieved = flops EXECUTED by the phase (structural zeros and the zero halves of the triangular blocks '
+                              'skipped; 60.8 % of the dense count N^2 (n_z+1)) / phase time from HIP events on the launch stream inside '
+                              'the timed steps (the events also bracket a memset and the O(N) build kernel, ~40 us)'}
+                     if trsm_flops else None),
+        'roofline_syrk': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<TN, lower tiles> = SYRK Hb = S^T S',
                      'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
                      'traffic': traffic, 'traffic_source': traffic_source, 'flops_per_launch': syrk_flops, 'dense_flops_per_launch': syrk_dense,
                      'dense_equivalent_tflops': syrk_dense / (syrk_ms * 1e-3) / 1e12, 'avg_launch_ms': syrk_ms,
@@ -282,6 +350,8 @@ def run_single(args, workload, comm=None):
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               'bytes_per_launch': 8.0 * N * N},
     }
+    if out['roofline'] is None:                                   # substitution schedule (debug): the SYRK is the measured GEMM then
+        out['roofline'] = out['roofline_syrk']
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(T, N, Nd, Nb, f, g, z0)
     ctx.close()
@@ -366,13 +436,19 @@ def run_sharded(args, workload, steps=None, warmup=None):
     S = torch.empty((N, lds), dtype=torch.float64, device=dev)
     Hb = torch.empty((nz + 1, lds), dtype=torch.float64, device=dev)
     delta = torch.empty(nz, dtype=torch.float64, device=dev)
+    # one-time companion of the factor: inverses of its 1024-row diagonal blocks (the column solves then are GEMMs only);
+    # S2 receives the solved block out of place and is zero where the solve never writes
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    Dinv = ops.trtri_diag(Theta, N, block=gpk.device.DINV_BLOCK)
+    torch.cuda.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
+    S2 = torch.zeros((N, lds), dtype=torch.float64, device=dev)
     losses = []
     for _ in range(warmup):
-        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True)[0])
+        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0])
     comm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True)[0])
+        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0])
     torch.cuda.synchronize(); comm.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -402,19 +478,19 @@ def run_sharded(args, workload, steps=None, warmup=None):
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
                        'parallelism': f'Theta: panel-sharded Cholesky (block-cyclic columns, width {args.panel}, RCCL broadcast); step: '
-                                      f'column-sharded TRSM + all-gather(S) + row-block-sharded SYRK + all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)',
+                                      f'column-sharded TRSM (GEMM-only, inverted 1024-row diagonal blocks of the factor) + all-gather(S) + row-block-sharded SYRK + all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)',
                        'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step, nothing cached across steps); structural zeros of A(z) '
                                       'skipped as on one GPU, column shards cut by work; f1_tflops is the dense-equivalent rate'},
             'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': warmup + steps,
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
             'f1_tflops': rate,
-            'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms},
+            'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'diagonal_block_inverses': dinv_ms},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step, dense F1 flops over all ranks)',
                          'achieved': rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
                          'frac': rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': None},
             'cpu_baseline': None,
         }
-    del S, Hb, Theta
+    del S, S2, Hb, Theta, Dinv
     torch.cuda.empty_cache()
     ctx.close()
     return out

@@ -1240,6 +1240,10 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 // upper triangles of the 512 x 512 diagonal blocks, which are computed and never read).
 int g_pipeline = 1;                                                  // gpk_debug_set key 12: 0 = SYRK, then right-looking Cholesky, on one stream
 int g_pipeline_chain_cus = 64;                                       // gpk_debug_set key 13: CUs of the chain partition (multiple of 8)
+// The partition costs the GEMM side a quarter of the chip, the chain side roughly doubles the time of its rank-64 updates;
+// the overlap pays while the panel chain (~34 us per 64 columns) is comparable to the GEMM work (~n^3): measured 4.24 -> 3.96 ms
+// at n = 4001 (BASELINE config 2) but 35.9 -> 43.8 ms at n = 10001, break-even near n = 5500.
+int g_pipeline_max_n = 5000;                                         // gpk_debug_set key 14: pipelined only up to this order
 
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
     int c = (g_pipeline_chain_cus / 8) * 8;
@@ -1271,7 +1275,7 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
     constexpr int OB = 512;
     const int J = gpk_ceil_div(nc, OB);
     h->pipe_tev_used = 0;
-    if (!g_pipeline || J < 3 || h->num_cu < 64) {                    // small systems: nothing to overlap
+    if (!g_pipeline || J < 3 || nc > g_pipeline_max_n || h->num_cu < 64) {   // small systems: nothing to overlap; large: see above
         if (h->prof) {
             while (h->pipe_tev.size() < 2) { hipEvent_t e; GPK_HIP(h, hipEventCreate(&e)); h->pipe_tev.push_back(e); }
             GPK_HIP(h, hipEventRecord(h->pipe_tev[0], h->stream));
@@ -1393,6 +1397,7 @@ extern "C" int gpk_debug_set_persistent_ob(int v) { g_persistent_ob = v; return 
 extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; return 0; }
 extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

@@ -499,6 +499,7 @@ extern "C" int gpk_debug_set_use_dinv(int v);
 extern "C" int gpk_debug_set_probe_chain_cus(int v);
 extern "C" int gpk_debug_set_pipeline(int v);
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
+extern "C" int gpk_debug_set_pipeline_max_n(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -514,6 +515,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 11) return gpk_debug_set_probe_chain_cus(value);
     if (key == 12) return gpk_debug_set_pipeline(value);
     if (key == 13) return gpk_debug_set_pipeline_chain_cus(value);
+    if (key == 14) return gpk_debug_set_pipeline_max_n(value);
     return GPK_ERR_ARG;
 }
 

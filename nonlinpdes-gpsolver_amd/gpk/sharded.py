@@ -120,6 +120,18 @@ class GpuBlockOps:
         """forward solve on the columns [c0, c0+ncols) of B; column c < lead (global index) is zero above row lead-1-c"""
         self.ctx._chk(self.lib.gpk_trsm_lz(self.h, self._p(L), n, L.stride(0), self._p(B, 0, c0), ncols, B.stride(0), int(lead - c0)))
 
+    def trtri_diag(self, L, n, block=1024):
+        """inverses of the block x block diagonal blocks of the factor L[:n, :n] -> (n, block) tensor (gpk_trtri_diag)"""
+        D = torch.empty((n, block), dtype=torch.float64, device=L.device)
+        self.ctx._chk(self.lib.gpk_trtri_diag(self.h, self._p(L), n, L.stride(0), D.data_ptr(), int(block)))
+        return D
+
+    def trsm_left_dinv(self, L, Dinv, n, B, X, c0, ncols, lead):
+        """X[:, c0:c0+ncols] <- L^{-1} B[:, c0:c0+ncols] with GEMMs only (gpk_trsm_dinv); B's columns become scratch.  lead > 0:
+        leading-zero right-hand sides as trsm_left_lz (lead is the global column index); X must be zero where never written."""
+        self.ctx._chk(self.lib.gpk_trsm_dinv(self.h, self._p(L), Dinv.data_ptr(), Dinv.stride(0), n, L.stride(0), self._p(B, 0, c0),
+                                             ncols, B.stride(0), self._p(X, 0, c0), X.stride(0), int(max(lead - c0, 0)) if lead else 0))
+
     def gram_tn_lz(self, Cm, cr, cc, m, n, k, A, ac, B, bc, lead):
         """gram_tn with operand B's column c < lead (global index) zero above row lead-1-c"""
         self.ctx._chk(self.lib.gpk_gemm_lz(self.h, 1, m, n, k, 1.0, self._p(A, 0, ac), A.stride(0), self._p(B, 0, bc), B.stride(0),
@@ -206,11 +218,13 @@ class ShardedFactorSolve:
         bounds.append(ncols)
         return bounds
 
-    def gn_step(self, prob_struct, nz, rows, L, z, S, Hb, delta, step_size, rev=False):
+    def gn_step(self, prob_struct, nz, rows, L, z, S, Hb, delta, step_size, rev=False, Dinv=None, S2=None):
         """One Gauss-Newton step with S column-sharded and Hb row-block-sharded; z is updated identically on all ranks.
         L: replicated factor (rows x rows); S: (rows, >= nz+1); Hb: (nz+1, >= nz+1); returns (loss_in, info).
         rev (elliptic system): unknown j lives in column nz-1-j of S, which makes column c zero above row nz-1-c; the
-        solves and products skip those zeros (28 % of the flops) and the column shards are cut by work, not by width."""
+        solves and products skip those zeros (28 % of the flops) and the column shards are cut by work, not by width.
+        Dinv (ops.trtri_diag(L)) + S2 (zero-initialised, same shape as S, reused across steps): the column solves run through
+        the inverted diagonal blocks (GEMMs only) out of place into S2, which then takes S's role; S is scratch."""
         ops, comm, P, rank, nb = self.ops, self.comm, self.P, self.rank, self.nb
         nc = nz + 1
         if rev:
@@ -222,11 +236,16 @@ class ShardedFactorSolve:
             bounds = [min(r * per0, nc) for r in range(P)] + [nc]
         c0, c1 = bounds[rank], bounds[rank + 1]
         per = max(bounds[r + 1] - bounds[r] for r in range(P))
+        use_dinv = Dinv is not None and S2 is not None
         if c1 > c0:                                                # my columns of L^{-1}[A | F]
-            if rev:
+            if use_dinv:
+                ops.trsm_left_dinv(L, Dinv, rows, S, S2, c0, c1 - c0, nz if rev else 0)
+            elif rev:
                 ops.trsm_left_lz(L, rows, S, c0, c1 - c0, nz)
             else:
                 ops.trsm_left(L, rows, S, c0, c1 - c0)
+        if use_dinv:
+            S = S2                                                 # the solved block lives in S2 from here on
         if P > 1:                                                  # all-gather the column shards of S (padded to the widest)
             mine = torch.zeros((rows, per), dtype=torch.float64, device=S.device)
             if c1 > c0:

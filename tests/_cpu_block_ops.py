@@ -64,6 +64,30 @@ class NumpyBlockOps:
         for c in range(c0, min(c0 + ncols, lead)):
             assert not np.any(b[:max(0, lead - 1 - c), c])
 
+    def trtri_diag(self, L, n, block=1024):
+        import torch
+        D = np.zeros((n, block))
+        l = np.tril(L.numpy()[:n, :n])
+        for k0 in range(0, n, block):
+            nk = min(block, n - k0)
+            D[k0:k0 + nk, :nk] = solve_triangular(l[k0:k0 + nk, k0:k0 + nk], np.eye(nk), lower=True, check_finite=False)
+        return torch.from_numpy(D)
+
+    def trsm_left_dinv(self, L, Dinv, n, B, X, c0, ncols, lead):
+        """blocked forward substitution through the inverted diagonal blocks, out of place (B becomes scratch); checks that the
+        part of X it does not write (left of the leading-zero boundary) is zero on entry"""
+        b, x, l, d = B.numpy(), X.numpy(), L.numpy(), Dinv.numpy()
+        db = d.shape[1]
+        cols = slice(c0, c0 + ncols)
+        for c in range(c0, min(c0 + ncols, lead)):
+            assert not np.any(x[:max(0, lead - 1 - c), c]), 'X not zero above the leading-zero boundary'
+        for k0 in range(0, n, db):
+            nk = min(db, n - k0)
+            x[k0:k0 + nk, cols] = d[k0:k0 + nk, :nk] @ b[k0:k0 + nk, cols]
+            if k0 + nk < n:
+                b[k0 + nk:n, cols] -= l[k0 + nk:n, k0:k0 + nk] @ x[k0:k0 + nk, cols]
+        b[:n, cols] = np.nan                                       # scratch: nobody may read it afterwards
+
     def gram_tn_lz(self, Cm, cr, cc, m, n, k, A, ac, B, bc, lead):
         self.gram_tn(Cm, cr, cc, m, n, k, A, ac, B, bc)
 

@@ -109,7 +109,12 @@ def test_gauss_newton_reaches_truth_full_size(setup):
         assert info == 0
         hist.append(loss)
     hist.append(ctx.gn_loss(prob, z))
-    assert all(b <= a * (1 + 1e-9) for a, b in zip(hist[3:], hist[4:]))          # monotone once past the first steps
+    # monotone once past the first steps.  The in-step loss is the squared norm of the F column of the solved block, which
+    # the GEMM-only solve (inverted diagonal blocks) delivers to ~1e-8 relative at this nugget: near convergence L^{-1}F is
+    # tiny against cond(L) |F|, the one case where multiplying by an explicit inverse loses against substitution (the iterate
+    # is not affected: the error of S^T w lies in the range of S^T, where H is large).  gn_loss (substitution) is exact:
+    assert all(b <= a * (1 + 1e-7) for a, b in zip(hist[3:], hist[4:]))
+    assert abs(hist[-1] - hist[-2]) <= 1e-7 * hist[-1]
     sol = z.download()
     err = O.elliptic_truth(Xd[:, 0], Xd[:, 1]) - sol
     assert np.sqrt(np.sum(err ** 2) / ND) < 1e-6

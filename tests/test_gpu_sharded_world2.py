@@ -65,11 +65,13 @@ WORKER = textwrap.dedent('''
     delta = torch.empty(nz, dtype=torch.float64, device=dev)
     z0 = rng.normal(size=nz)
     sol_ref, hist_ref = O.gn_method(sysm, [Lref], z0, 3, 1)
-    for rev in (False, True):
+    Dinv = ops.trtri_diag(Lt, N, block=256)                     # N > 256: several inverted blocks + a ragged last one
+    for rev, dinv in ((False, False), (True, False), (False, True), (True, True)):
         z = t(z0)
+        S2 = torch.zeros_like(S) if dinv else None
         hist = []
         for _ in range(3):
-            loss_in, info = solver.gn_step(ps, nz, N, Lt, z, S, Hb, delta, 1.0, rev=rev)
+            loss_in, info = solver.gn_step(ps, nz, N, Lt, z, S, Hb, delta, 1.0, rev=rev, Dinv=Dinv if dinv else None, S2=S2)
             assert info == 0
             hist.append(loss_in)
         np.testing.assert_allclose(hist, hist_ref[:3], rtol=1e-6)

@@ -74,11 +74,13 @@ def _worker(rank, world, port, case, out_dir):
             Hb = torch.zeros((nz + 1, nz + 4), dtype=torch.float64)
             delta = torch.zeros(nz, dtype=torch.float64)
             sol_ref, hist_ref = O.gn_method(sysm, [O.cholesky(Theta)], z0, 3, 1)
-            for rev in (False, True):                             # plain layout and the leading-zero (reversed) layout
+            Dinv = solver.ops.trtri_diag(Lt, N, block=32)         # (the test double takes any block size)
+            for rev, dinv in ((False, False), (True, False), (False, True), (True, True)):   # plain / leading-zero layout, substitution / inverted blocks
                 z = torch.from_numpy(z0.copy())
+                S2 = torch.zeros_like(S) if dinv else None
                 hist = []
                 for _ in range(3):
-                    loss_in, info = solver.gn_step(None, nz, N, Lt, z, S, Hb, delta, 1.0, rev=rev)
+                    loss_in, info = solver.gn_step(None, nz, N, Lt, z, S, Hb, delta, 1.0, rev=rev, Dinv=Dinv if dinv else None, S2=S2)
                     assert info == 0
                     hist.append(loss_in)
                 np.testing.assert_allclose(hist, hist_ref[:3], rtol=1e-7)
