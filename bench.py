@@ -172,15 +172,17 @@ class AbortWatch:
         self.rank, self.out = rank, primary_out
         self.store = dist.distributed_c10d._get_default_store()
         self.done = threading.Event()
+        self.lock = threading.Lock()                              # main thread and watcher may both get here: ONE line only
         self.thread = threading.Thread(target=self._poll, daemon=True)
         self.thread.start()
 
     def _finish(self, msg):
-        if self.rank == 0 and self.out is not None:
-            self.out['sharded_config'] = {'error': msg}
-            print(json.dumps(self.out), flush=True)
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        with self.lock:                                           # never released: the process ends inside
+            if self.rank == 0 and self.out is not None:
+                self.out['sharded_config'] = {'error': msg}
+                print(json.dumps(self.out), flush=True)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
 
     def _poll(self):
         while not self.done.wait(0.5):
@@ -191,9 +193,13 @@ class AbortWatch:
                 return
 
     def fail(self, msg):
-        """called by the rank that caught the exception"""
+        """called by the rank that caught the exception; if a peer reported first, its message is the cause (this rank most
+        likely only saw the peer's connection close)"""
         try:
-            self.store.set(self.KEY, msg)
+            if self.store.check([self.KEY]):
+                msg = self.store.get(self.KEY).decode(errors='replace')
+            else:
+                self.store.set(self.KEY, msg)
         except Exception:
             pass
         self._finish(msg)
