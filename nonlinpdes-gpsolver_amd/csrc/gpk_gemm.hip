@@ -43,6 +43,7 @@ struct GemmArgs {
                        // lower tiles: the A tile's columns are further right, i.e. non-zero even earlier.)
     int skip_upper;    // C is a block column whose top square is a diagonal block of a symmetric matrix: tiles entirely above
                        // that diagonal (m0 + BM <= n0) are not computed (their content is never read)
+    int stagger;       // experiment, see the kernel
     int tri_a;         // operand A (TA = false, stored [m][k]) is lower triangular: row m has no entries at k > m, so the tile
                        // with rows [m0, m0+BM) stops its K loop at m0+BM (the explicit inverses of diagonal blocks, gpk_trsm_dinv)
     int vecA, vecB;
@@ -107,6 +108,7 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
 int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
+int g_stagger = 0;                                                   // gpk_debug_set key 15: start-time stagger of co-resident GEMM workgroups (experiment)
 int g_supertile = 0;                                                 // gpk_debug_set key 6: 1 = supertile schedule for the leading-zero SYRK (below)
 
 __device__ __forceinline__ bool map_tile(const GemmArgs& g, int& tm, int& tn) {
@@ -197,6 +199,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     // one tile per workgroup, the four tiles a CU received had the same t: 4..64 slabs against an average of 34).
     // (TRI is a template parameter and the tile body a lambda: as a runtime loop around the body it cost every instantiation
     // 30-50 VGPRs and a wave of occupancy)
+    if (g.stagger > 0) {
+        // EXPERIMENT (gpk_debug_set key 15, off by default): de-phase the workgroups that share a CU.  A one-wave launch with a
+        // long K loop (1008 tiles, K = 4352) runs in lock-step -- the four workgroups of a CU load, wait at their barrier and
+        // compute at the same moments -- and reaches 56-59 TFLOP/s; with a start-time stagger of slot x 1024 cycles it reaches
+        // 67 (tools/gemm_tail_probe.py; launches of >= 2 waves de-phase by themselves: 68-70 either way).  Inside the
+        // Gauss-Newton step the one-wave launches have K <= 1024 and the stagger changes nothing (per-launch times within 1 %),
+        // so it stays off.  The wave slot id (HW_REG_HW_ID[3:0]) differs between the co-resident workgroups.
+        const int slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 0xf;    // size 4, offset 0, register 4 (HW_ID)
+        for (int i = 0; i < (slot & 3) * g.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     auto tile = [&](const int tm) __attribute__((always_inline)) {
     const int m0 = tm * BM;
     if (g.skip_upper && m0 + BM <= n0) return;
@@ -516,6 +528,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 12) return gpk_debug_set_pipeline(value);
     if (key == 13) return gpk_debug_set_pipeline_chain_cus(value);
     if (key == 14) return gpk_debug_set_pipeline_max_n(value);
+    if (key == 15) { g_stagger = value; return 0; }
     return GPK_ERR_ARG;
 }
 
@@ -531,6 +544,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
+    g.stagger = g_stagger;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
     if (k <= 64 && !lower_only && !g.tri_a && !g.skip_upper && g_force_cfg == 0 &&

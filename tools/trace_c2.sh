@@ -1,3 +1,7 @@
+# kernel trace of the config-2 bench (development aid): gpurun_out/r02c/<tag>/ ; usage: trace_c2.sh <tag> [GPK_DEBUG_SET value]
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-sharded-config --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r02c/bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/r02c/err.txt
-ls -R $GRAFT_REPO_ROOT/gpurun_out/r02c | head
+TAG=${1:-default}
+export GPK_DEBUG_SET=${2:-}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r02c/$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-sharded-config --no-cpu-baseline > $OUT/bench.json 2> $OUT/err.txt
