@@ -72,7 +72,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
                const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0, bool tri_a = false,
                bool skip_upper = false);
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
-int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base);
+int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base, bool left_looking = false);
 // Hb <- chol(W^T W) (lower, nc x nc; W is rows x nc with the leading-zero shape `lead` of gpk_i_gemm), the product and the
 // factorisation pipelined by 512-column blocks on two CU partitions (gpk_factor.hip); d_loss (device, may be null) receives
 // the unfactored last diagonal entry (W^T W)[nc-1][nc-1]

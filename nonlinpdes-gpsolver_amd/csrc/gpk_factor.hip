@@ -953,6 +953,7 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
 int g_dbg = 0;
 int g_mt_trsm = 0;
 int g_persistent_ob = 0;                                             // gpk_debug_set key 7: 1 = persistent outer-block kernel (slower, see its header)
+int g_left_looking_panels = 1;                                       // gpk_debug_set key 18: 0 = right-looking rank-64 updates also in the pipelined chain
 int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
@@ -1165,7 +1166,7 @@ int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X
 // Factor a tall block column: D = A[0:ob, 0:ob] is replaced by its Cholesky factor and the rows below by A[ob:, 0:ob] D^{-T}
 // (64-column panel kernel + rank-64 update of the remaining columns, for all nrows rows).  The building block of both
 // the single-GPU factorisation below and the panel-sharded multi-GPU one (gpk/sharded.py, the owner's share of a step).
-int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base) {
+int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base, bool left_looking) {
     if (ob <= 0 || nrows < ob) return 0;
     if (g_persistent_ob) {
         if (++h->ob_epoch == 0x7fffffff) {
@@ -1180,6 +1181,15 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
         const int nb = (ob - j0 < NB) ? ob - j0 : NB;
         double* Ajj = A + (long)j0 * lda + j0;
         const int below = nrows - (j0 + nb);
+        if (left_looking && j0 > 0) {
+            // LEFT-looking inside the block column (used when the chain runs on the small CU partition of the pipeline): the
+            // 64 columns of this panel receive the contributions of all earlier panels of the block in one product with K = j0
+            // <= 448 and rows/32 workgroups, instead of every panel pushing a rank-64 update into all remaining columns (up to
+            // 7 x rows/32 workgroups, which a 32-CU partition works off in several rounds: 20-30 us instead of 9).  Same flops.
+            // On the whole chip the right-looking form is faster (the long-K product on ~110 workgroups is latency-bound:
+            // 4.42 vs 4.25 ms for the phase), so it remains the default everywhere else.
+            GPK_TRY(gpk_i_gemm(h, false, true, nrows - j0, nb, j0, -1.0, A + (long)j0 * lda, lda, A + (long)j0 * lda, lda, 1.0, Ajj, lda, false));
+        }
         if (g_fused_panel) {
             const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
             const unsigned target = h->panel_loaded + (unsigned)nrb;
@@ -1192,7 +1202,7 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             if (below > 0)
                 trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, g_dbg);
         }
-        if (below > 0) {
+        if (below > 0 && !left_looking) {
             double* Abj = A + (long)(j0 + nb) * lda + j0;
             const int pc = ob - (j0 + nb);                           // remaining columns of this block column
             if (pc > 0) {
@@ -1239,10 +1249,11 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 // The chain of block j runs next to S_{j+1} and the early part of U_{j+1}.  Same flops as the right-looking order (plus the
 // upper triangles of the 512 x 512 diagonal blocks, which are computed and never read).
 int g_pipeline = 1;                                                  // gpk_debug_set key 12: 0 = SYRK, then right-looking Cholesky, on one stream
-int g_pipeline_chain_cus = 64;                                       // gpk_debug_set key 13: CUs of the chain partition (multiple of 8)
+int g_pipeline_chain_cus = 32;                                       // gpk_debug_set key 13: CUs of the chain partition (multiple of 8)
 // The partition costs the GEMM side a quarter of the chip, the chain side roughly doubles the time of its rank-64 updates;
 // the overlap pays while the panel chain (~34 us per 64 columns) is comparable to the GEMM work (~n^3): measured 4.24 -> 3.96 ms
 // at n = 4001 (BASELINE config 2) but 35.9 -> 43.8 ms at n = 10001, break-even near n = 5500.
+int g_pipeline_pre = 1;                                              // gpk_debug_set key 17: blocks of the product computed before the fork
 int g_pipeline_max_n = 5000;                                         // gpk_debug_set key 14: pipelined only up to this order
 
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
@@ -1287,22 +1298,39 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
     }
     GPK_TRY(pipe_setup(h, 2 * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
     const hipStream_t main_s = h->stream, G = h->pipe_g, C = h->pipe_c;
-    auto product = [&](int j) {                                      // S_j (tiles above the diagonal of the block are skipped)
-        const int j0 = j * OB, ob = (nc - j0 < OB) ? nc - j0 : OB, m = nc - j0;
-        return gpk_i_gemm(h, true, false, m, ob, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
+    // product of the blocks [jb, je): Hb[jb OB :, jb OB : je OB] = W[:, jb OB :]^T W[:, jb OB : je OB] (tiles above the diagonal skipped)
+    auto product = [&](int jb, int je) {
+        const int j0 = jb * OB, j1 = (je * OB < nc) ? je * OB : nc;
+        return gpk_i_gemm(h, true, false, nc - j0, j1 - j0, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
                           lead > j0 ? lead - j0 : 0, false, true);
     };
     hipEvent_t* ev_ready = h->pipe_ev.data();                        // [J]
     hipEvent_t* ev_chain = h->pipe_ev.data() + J;                    // [J]
     hipEvent_t ev_fork = h->pipe_ev[2 * J];
-    int rc = 0;
+    int rc = 0, ntev = 0;
     auto fail = [&](hipError_t e, const char* what) { h->stream = main_s; return gpk_fail(h, e, what, __FILE__, __LINE__); };
 #define PIPE_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
-    // block 0 has nothing to overlap with: its product runs on the whole chip, before the fork
-    if (h->prof) PIPE_HIP(hipEventRecord(h->pipe_tev[0], main_s));
-    rc = product(0);
+    auto timed_product = [&](hipStream_t s, int jb, int je) -> int {  // (HIP events around the launch: bench.py's roofline leg)
+        if (h->prof) { hipError_t e = hipEventRecord(h->pipe_tev[ntev], s); if (e != hipSuccess) return fail(e, "hipEventRecord"); }
+        const int r = product(jb, je);
+        if (h->prof) {
+            hipError_t e = hipEventRecord(h->pipe_tev[ntev + 1], s); if (e != hipSuccess) return fail(e, "hipEventRecord");
+            ntev += 2; h->pipe_tev_used = ntev;
+        }
+        if (r == 0 && je >= J && d_loss) {                           // the bordered matrix' last diagonal entry, before any update
+            hipError_t e = hipMemcpyAsync(d_loss, Hb + (long)(nc - 1) * ldh + (nc - 1), sizeof(double), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return fail(e, "hipMemcpyAsync");
+        }
+        return r;
+    };
+    // The first `pre` blocks of the product run on the whole chip before the fork (one launch): nothing could overlap with
+    // block 0.  Measured at config 2 (phase time, ms): pre = 1 / 2 / 3 -> 4.01 / 4.16 / 4.37 with a 64-CU chain partition; with
+    // the left-looking chain, pre = 1 and chain partitions of 16 / 24 / 32 / 40 / 64 CUs -> 4.65 / 4.06 / 3.88 / 3.98 / 4.10;
+    // sequential (one stream, whole chip) 4.25.
+    int pre = g_pipeline_pre < 1 ? 1 : g_pipeline_pre;
+    if (pre > J - 1) pre = J - 1;
+    rc = timed_product(main_s, 0, pre);
     if (rc) return rc;
-    if (h->prof) { PIPE_HIP(hipEventRecord(h->pipe_tev[1], main_s)); h->pipe_tev_used = 2; }
     PIPE_HIP(hipEventRecord(ev_fork, main_s));
     PIPE_HIP(hipStreamWaitEvent(G, ev_fork, 0));
     PIPE_HIP(hipStreamWaitEvent(C, ev_fork, 0));
@@ -1310,14 +1338,6 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
         const int j0 = j * OB, ob = (nc - j0 < OB) ? nc - j0 : OB, m = nc - j0;
         double* Hjj = Hb + (long)j0 * ldh + j0;
         h->stream = G;
-        if (j > 0) {
-            if (h->prof) PIPE_HIP(hipEventRecord(h->pipe_tev[2 * j], G));
-            rc = product(j);
-            if (h->prof) { PIPE_HIP(hipEventRecord(h->pipe_tev[2 * j + 1], G)); h->pipe_tev_used = 2 * (j + 1); }
-            if (rc) break;
-        }
-        if (j == J - 1 && d_loss)
-            PIPE_HIP(hipMemcpyAsync(d_loss, Hb + (long)(nc - 1) * ldh + (nc - 1), sizeof(double), hipMemcpyDeviceToDevice, G));
         if (j > 0) {
             const double* Lrow = Hb + (long)j0 * ldh;                // rows j0.. of the factored panels, columns 0..j0
             if (j > 1) {                                             // panels 0..j-2: their chain finished an iteration ago
@@ -1329,9 +1349,13 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
             if (rc) break;
         }
         PIPE_HIP(hipEventRecord(ev_ready[j], G));
+        if (j + pre < J) {                                           // product of the block `pre` ahead, while the chain of block j runs
+            rc = timed_product(G, j + pre, j + pre + 1);
+            if (rc) break;
+        }
         h->stream = C;
         PIPE_HIP(hipStreamWaitEvent(C, ev_ready[j], 0));
-        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, j0);
+        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, j0, g_left_looking_panels != 0);
         if (rc) break;
         PIPE_HIP(hipEventRecord(ev_chain[j], C));
     }
@@ -1398,6 +1422,8 @@ extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; ret
 extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0; }
+extern "C" int gpk_debug_set_left_looking_panels(int v) { g_left_looking_panels = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

@@ -44,6 +44,9 @@ struct GemmArgs {
     int skip_upper;    // C is a block column whose top square is a diagonal block of a symmetric matrix: tiles entirely above
                        // that diagonal (m0 + BM <= n0) are not computed (their content is never read)
     int stagger;       // experiment, see the kernel
+    int rev_k;         // leading-zero operands: the K range of a tile is [k0(column), K) with a different k0 per column tile, so
+                       // tiles that start together walk different slabs at any moment and share nothing in L2.  Walking K
+                       // DOWNWARDS from the common end K aligns them: concurrently started tiles read the same slabs of A.
     int tri_a;         // operand A (TA = false, stored [m][k]) is lower triangular: row m has no entries at k > m, so the tile
                        // with rows [m0, m0+BM) stops its K loop at m0+BM (the explicit inverses of diagonal blocks, gpk_trsm_dinv)
     int vecA, vecB;
@@ -108,6 +111,7 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
 int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
+int g_rev_k = 0;                                                     // gpk_debug_set key 16
 int g_stagger = 0;                                                   // gpk_debug_set key 15: start-time stagger of co-resident GEMM workgroups (experiment)
 int g_supertile = 0;                                                 // gpk_debug_set key 6: 1 = supertile schedule for the leading-zero SYRK (below)
 
@@ -278,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             const long sa = !TA ? (long)BK : (long)BK * g.lda, sb = TB ? (long)BK : (long)BK * g.ldb;
             d2 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
             auto load = [&](int kt, d2 (&ra)[NA], d2 (&rb)[NB]) {
-                const int kc = min(kt, nkf - 1);                      // past the end: re-read the last slab (never used)
+                int kc = min(kt, nkf - 1);                            // past the end: re-read the last slab (never used)
+                if (g.rev_k) kc = (nkf - 1) - (kc - kt0);             // walk K downwards (see GemmArgs::rev_k)
 #pragma unroll
                 for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const d2*>(pa[i] + kc * sa);
 #pragma unroll
@@ -512,6 +517,8 @@ extern "C" int gpk_debug_set_probe_chain_cus(int v);
 extern "C" int gpk_debug_set_pipeline(int v);
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
 extern "C" int gpk_debug_set_pipeline_max_n(int v);
+extern "C" int gpk_debug_set_pipeline_pre(int v);
+extern "C" int gpk_debug_set_left_looking_panels(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -529,6 +536,9 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 13) return gpk_debug_set_pipeline_chain_cus(value);
     if (key == 14) return gpk_debug_set_pipeline_max_n(value);
     if (key == 15) { g_stagger = value; return 0; }
+    if (key == 17) return gpk_debug_set_pipeline_pre(value);
+    if (key == 18) return gpk_debug_set_left_looking_panels(value);
+    if (key == 16) { g_rev_k = value; return 0; }
     return GPK_ERR_ARG;
 }
 
@@ -545,6 +555,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.stagger = g_stagger;
+    g.rev_k = (g_rev_k && g.lead > 0) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
     if (k <= 64 && !lower_only && !g.tri_a && !g.skip_upper && g_force_cfg == 0 &&

@@ -20,8 +20,12 @@ VARIANTS = [
     ('persistent outer-block Cholesky kernel (flag-chained workgroups)', {7: 1}),
     ('substitution strips instead of the inverted diagonal blocks', {10: 0}),
     ('substitution, 64-row base solves', {10: 0, 3: 0}),
+    ('product then right-looking factorisation on one stream (no CU-partition pipeline)', {12: 0}),
+    ('right-looking rank-64 updates inside the block columns of the pipelined factorisation', {18: 0}),
+    ('pipeline with two pre-fork blocks and a 64-CU chain partition', {17: 2, 13: 64}),
+    ('leading-zero products walking K downwards', {16: 1}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 5000, 16: 0, 17: 1, 18: 1}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
@@ -52,7 +56,7 @@ def test_schedule_variants_agree():
     ctx = gpk.Context(0)
     np.random.seed(5)
     from src.sample_points import sampled_pts_rdm
-    Nd, Nb = 1100, 160                                           # N = 2360 (10 strips), n_z = 1100 (18 panels / TRSV blocks)
+    Nd, Nb = 1100, 160                                           # N = 2360 (10 strips), n_z = 1100 (18 panels / TRSV blocks, 3 pipeline blocks)
     Xd, Xb = sampled_pts_rdm(Nd, Nb, np.array([[0, 1], [0, 1]]))
     f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
     init = np.random.normal(0.0, 1.0, Nd)
