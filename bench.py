@@ -142,19 +142,22 @@ def trsm_dinv_executed_flops(N, nz, db=1024, num_cu=256, nb=64, bk=16):
     return acc[0], acc[1]
 
 
-def stored_pmc_traffic():
+def stored_pmc_traffic(which='syrk'):
     """`roofline.traffic` cannot be measured inside this process (PMC counters need a rocprofv3 --pmc pass of their own,
-    tools/profile_round.sh): it is READ from the newest committed profiles/rNN_pmc_syrk.json and labelled as such."""
+    tools/profile_round.sh): it is READ from the newest committed profiles/rNN_pmc_<which>.json -- HBM-side bytes per
+    Gauss-Newton step of that kernel family (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) -- and labelled as such."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_syrk.json')))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_pmc_{which}.json')))
     for path in reversed(files):
         try:
-            v = json.load(open(path)).get('hbm_bytes_per_launch')
+            d = json.load(open(path))
         except Exception:
             continue
+        v = d.get('hbm_bytes_per_step', d.get('hbm_bytes_per_launch'))
         if v is not None:
+            per = 'step (sum over the launches of this kernel in one Gauss-Newton step)' if 'hbm_bytes_per_step' in d else 'launch'
             return v, (f'stored PMC pass profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same '
-                       f'kernel at this workload); not measured in this run')
+                       f'kernel at this workload), bytes per {per}; not measured in this run')
     return None, 'no stored PMC pass found'
 
 
@@ -301,7 +304,8 @@ def run_single(args, workload, comm=None):
     syrk_launched = syrk_pipelined_flops(N, nz) if pipelined else syrk_flops
     syrk_dense = float(N) * (nz + 1) ** 2                        # dense symmetric count, SURVEY 8d ("SYRK N n_z^2")
     achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12
-    traffic, traffic_source = stored_pmc_traffic()
+    traffic, traffic_source = stored_pmc_traffic('syrk')
+    trsm_traffic, trsm_traffic_source = stored_pmc_traffic('trsm_gemm')
     # dominant kernel of the step: gemm_f64_kernel<NN> = the whole solve phase S = L^{-1}[A | F] (GEMMs only since round 2)
     trsm_ms = prof['trsm_ms'] / steps
     uses_dinv = prob.Dinv is not None and os.environ.get('GPK_DEBUG_SET', '').find('10=0') < 0
@@ -331,7 +335,7 @@ def run_single(args, workload, comm=None):
                       'kernel': 'gemm_f64_kernel<.., NN> = the solve phase S = L^{-1}[A | F]: update products of the recursion and '
                                 'triangular products with the inverted diagonal blocks of the factor, all fp64 MFMA',
                       'achieved': trsm_achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': trsm_achieved / FP64_MFMA_PEAK_TFLOPS,
-                      'traffic': None, 'traffic_source': 'not collected for this kernel family (PMC pass of the SYRK kernel: roofline_syrk)',
+                      'traffic': trsm_traffic, 'traffic_source': trsm_traffic_source,
                       'flops_per_step': trsm_flops, 'launches_per_step': trsm_launches, 'phase_ms_per_step': trsm_ms,
                       'avg_launch_ms': trsm_ms / trsm_launches,
                       'dense_flops_per_step': float(N) * N * (nz + 1), 'dense_equivalent_tflops': float(N) * N * (nz + 1) / (trsm_ms * 1e-3) / 1e12,
