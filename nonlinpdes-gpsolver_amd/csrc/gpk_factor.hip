@@ -12,6 +12,7 @@
 //   trsm_right_lt = X1 <- X1 L11^{-T}; X2 -= X1 L21^T; X2 <- X2 L22^{-T}
 // The recursion splits at multiples of 64/128 so that sub-blocks stay 16-byte aligned for the GEMM's vector loads.
 #include "gpk_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -396,10 +397,13 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     __shared__ __attribute__((aligned(16))) double Ps[8 * NB];       // potf2_tile's column exchange: 2 parities x 4 vectors
     __builtin_amdgcn_s_setprio(3);                                   // latency chain: win issue arbitration against co-resident GEMM waves
     const int c0 = ((int)blockIdx.x - 1) * NB;                       // blocks > 0: my 64 rows below the diagonal block
+#define PANEL_STAMP(i) do { if (dbg && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
+    PANEL_STAMP(0);
     double xr[16];
     if (blockIdx.x > 0) potf2_fetch_extra(A + (long)(nb + c0) * lda, lda, min(NB, below - c0), nb, xr);   // same round trip as A_jj
     potf2_stage(A, lda, nb, As);
     __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
+    PANEL_STAMP(1);
     if (blockIdx.x == 0) {
         const int bad = potf2_tile<false>(As, Ps, nb);
         __shared__ int expired;
@@ -421,6 +425,279 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     } else {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         potf2_tile<true>(As, Ps, nb, A + (long)(nb + c0) * lda, lda, min(NB, below - c0), &xr);
+        PANEL_STAMP(2);
+    }
+}
+
+// ---- Cholesky panel step, second design (round 2): narrow panels factored inside ONE wave, MFMA trailing updates ------------
+// Same contract as potrf_panel_kernel (workgroup 0 factors A_jj in place, workgroup b > 0 factors its own copy and its 64 rows
+// below ride along; load tickets protect the in-place store).  What changed is the inside: potf2_tile spends ~720 cycles per
+// column (stamps: 46 k cycles for 64 columns with the extra rows) because every pair of columns is an LDS exchange + workgroup
+// barrier between an rsqrt chain and a rank-2 update that runs serially behind it.  Here
+//   * the 128 x 64 working set (64 rows of A_jj + 64 extra rows) lives in MFMA accumulators for the whole kernel: wave w owns the
+//     rows 32w .. 32w+31 (waves 0-1 the diagonal block, waves 2-3 the extra rows), 2 x 4 tiles of 16 x 16;
+//   * a panel of PW columns is handed to WAVE 0 through LDS in "lane = row" form -- lane i holds row i of A_jj AND row i of the
+//     extra block -- and is factored there right-looking with no LDS traffic and no barrier: the pivot and the multipliers
+//     l[c][j] are wave-uniform (v_readlane from the lane that owns row c), the extra rows take the same operations in a second
+//     register set;
+//   * the factored panel goes back to LDS once and every wave subtracts it from its trailing tiles with v_mfma_f64_16x16x4_f64
+//     (K = PW); the tile that holds the NEXT panel is updated and staged for wave 0 right away, the other tiles are updated
+//     while wave 0 factors the next panel (between the two barriers of the next round).
+// Two workgroup barriers per PW columns instead of one per 2.  Measured (shader-clock stamps, tools/panel_stamp_probe.py, 64 columns
+// with extra rows): first design 46 k cycles; PW = 16: 45.6 k (wave 0 alone issues 436 v_readlane + 288 v_fma_f64 per panel, 495
+// cycles per column, plus SGPR spills of the multipliers); PW = 8: 38-42 k = per panel ~2050 cycles of factorisation in wave 0
+// (259 per column) + ~600 until the slowest wave has finished its deferred updates + ~1950 for the hand-over (LDS operand
+// reads -> two dependent MFMAs -> accumulator read-back -> staging writes -> barrier -> wave 0's reads: a chain of LDS and MFMA
+// latencies that neither batching the reads nor compile-time tile ranges shortened).  End to end at config 2: product +
+// factorisation 3.94 -> 3.83-3.92 ms, Cholesky of Theta 9.35-9.4 -> 9.13-9.16 ms.  The hand-over is what to attack next.
+template <int PW>
+__device__ __forceinline__ int panel_factor_lane_rows(double* __restrict__ Pc, int p, int l) {
+    constexpr int PSW = PW + 2;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double a[PW], x[PW];
+#pragma unroll
+    for (int i = 0; i < PW / 2; ++i) {
+        const d2 t = *reinterpret_cast<const d2*>(Pc + l * PSW + 2 * i);
+        a[2 * i] = t.x; a[2 * i + 1] = t.y;
+        const d2 u = *reinterpret_cast<const d2*>(Pc + (64 + l) * PSW + 2 * i);
+        x[2 * i] = u.x; x[2 * i + 1] = u.y;
+    }
+    int bad = 0;
+    const int cb = __builtin_amdgcn_readfirstlane(PW * p);
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int col = cb + j;
+        const double d = bcast_lane(a[j], col);                      // pivot (wave-uniform)
+        if (!(d > 0.0) && bad == 0) bad = col + 1;
+        const double y0 = __builtin_amdgcn_rsq(d);
+        double g = d * y0, hh = 0.5 * y0;
+        double e = fma(-g, hh, 0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        e = fma(-g, hh, 0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        const double sq = fma(fma(-g, g, d), hh, g);
+        const double rinv = hh + hh;
+        a[j] = (l == col) ? sq : a[j] * rinv;
+        x[j] = x[j] * rinv;
+#pragma unroll
+        for (int c = j + 1; c < PW; ++c) {
+            const double m = bcast_lane(a[j], cb + c);               // l[cb+c][col]
+            a[c] = fma(-a[j], m, a[c]);
+            x[c] = fma(-x[j], m, x[c]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PW / 2; ++i) {
+        *reinterpret_cast<d2*>(Pc + l * PSW + 2 * i) = (d2){a[2 * i], a[2 * i + 1]};
+        *reinterpret_cast<d2*>(Pc + (64 + l) * PSW + 2 * i) = (d2){x[2 * i], x[2 * i + 1]};
+    }
+    return bad;
+}
+
+template <int PW>
+__global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, int nb, int below,
+                                                               int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
+    static_assert(PW == 8 || PW == 16, "panel width");
+    constexpr int PSW = PW + 2;                                      // row stride of a panel buffer: 16-byte aligned rows, conflict-free b64 reads
+    constexpr int KS = PW / 4;                                       // MFMA k-steps per panel
+    constexpr int HPT = 16 / PW;                                     // panels per 16-column tile
+    __shared__ __attribute__((aligned(16))) double Pb[2][128 * PSW];
+    __shared__ int sh_bad, sh_expired;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = l & 15, lk = l >> 4;
+    const bool tall = blockIdx.x > 0;
+    const int c0 = ((int)blockIdx.x - 1) * NB;
+    const int xrows = tall ? min(NB, below - c0) : 0;
+    double* __restrict__ Xg = A + (long)(nb + (tall ? c0 : 0)) * lda;   // my 64 rows below the diagonal block
+    const bool rows_diag = (w < 2);                                  // waves 0, 1: rows of A_jj; waves 2, 3: extra rows
+    const bool active = rows_diag || tall;
+#define PANEL_STAMP(i) do { if (dbg && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
+    PANEL_STAMP(0);
+    if (tid == 0) sh_bad = 0;
+
+    // ---- load into accumulator layout: tile (rt, ct) lane l reg r = row 32w + 16rt + lk + 4r, column 16ct + li.  Branch-free
+    // (clamped addresses, all 32 loads in flight at once; with the loads inside if/else arms the compiler waited for each one)
+    d4 acc[2][4];
+    {
+        const double* __restrict__ base = (rows_diag || !tall) ? A : Xg;     // (waves 2, 3 of workgroup 0 read A and discard it)
+        const int rmax = (rows_diag || !tall) ? nb - 1 : xrows - 1;
+        const int rlim = rows_diag ? nb : xrows;                              // rows >= rlim are padding (workgroup 0, waves 2-3: xrows = 0)
+        const int rbase = 32 * (w & 1) + lk;                                  // row inside my 64-row block (A_jj or extra rows)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
+                    acc[rt][ct][r] = base[(long)min(row, rmax) * lda + min(col, nb - 1)];
+                }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
+                    const double pad = (rows_diag && row == col) ? 1.0 : 0.0;    // identity padding of A_jj, zero padding of the extra rows
+                    acc[rt][ct][r] = (row < rlim && col < nb) ? acc[rt][ct][r] : pad;
+                }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // my loads of A_jj have landed
+    // my two tiles of one column tile -> the PW columns of panel q in P[row][PW] (lanes of the other half of the tile sit out)
+    auto stage = [&](double* __restrict__ P, int q, const d4 (&t0), const d4 (&t1)) {
+        if (HPT == 1 || (li / PW) == (q % HPT)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                P[(32 * w + lk + 4 * r) * PSW + (li % PW)] = t0[r];
+                P[(32 * w + 16 + lk + 4 * r) * PSW + (li % PW)] = t1[r];
+            }
+        }
+    };
+    // Trailing update of my tiles with the panel in P: acc[rt][ct] -= P[my rows of tile rt] * P[rows 16ct .. 16ct+15]^T for the column
+    // tiles LO..HI (compile-time: with run-time bounds the compiler turned the tile loop into branchy code with one LDS wait per
+    // tile, 2000+ cycles for four MFMAs).  All LDS operands are requested first (one latency), then the MFMAs run back to back.
+    // Tiles of A_jj strictly above the diagonal are never used and skipped (wave-uniform tests).
+    auto update_static = [&](const double* __restrict__ P, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        double a0[KS], a1[KS], bf[4][KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a0[ks] = -P[(32 * w + li) * PSW + 4 * ks + lk];
+            a1[ks] = -P[(32 * w + 16 + li) * PSW + 4 * ks + lk];
+        }
+#pragma unroll
+        for (int ct = LO; ct <= HI; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bf[ct][ks] = P[(16 * ct + li) * PSW + 4 * ks + lk];   // (rows < 64 always exist in the buffer)
+#pragma unroll
+        for (int ct = LO; ct <= HI; ++ct) {
+            if (16 * ct < nb) {
+                if (!rows_diag || 2 * w >= ct) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], bf[ct][ks], acc[0][ct], 0, 0, 0);
+                }
+                if (!rows_diag || 2 * w + 1 >= ct) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], bf[ct][ks], acc[1][ct], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto update_from = [&](const double* __restrict__ P, int lo, bool to_end) {     // tiles lo..(to_end ? 3 : lo), dispatched to static code
+        using std::integral_constant;
+        if (to_end) {
+            switch (lo) {
+                case 0: update_static(P, integral_constant<int, 0>{}, integral_constant<int, 3>{}); break;
+                case 1: update_static(P, integral_constant<int, 1>{}, integral_constant<int, 3>{}); break;
+                case 2: update_static(P, integral_constant<int, 2>{}, integral_constant<int, 3>{}); break;
+                case 3: update_static(P, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
+                default: break;
+            }
+        } else {
+            switch (lo) {
+                case 0: update_static(P, integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+                case 1: update_static(P, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+                case 2: update_static(P, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+                case 3: update_static(P, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
+                default: break;
+            }
+        }
+    };
+    if (active) stage(Pb[0], 0, acc[0][0], acc[1][0]);
+    __syncthreads();
+    if (tall && tid == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket: A_jj has been read
+    PANEL_STAMP(1);
+
+    const int npan = (nb + PW - 1) / PW;
+    // (a ROLLED loop over the panels: the factorisation code of wave 0 exists once; every accumulator index below is static, the
+    // panel index only appears in wave-uniform tests)
+#pragma unroll 1
+    for (int p = 0; p < npan; ++p) {
+        double* __restrict__ Pc = Pb[p & 1];                         // panel p (staged; factored between the barriers)
+        double* __restrict__ Pq = Pb[(p + 1) & 1];                   // panel p-1 (still needed for the deferred updates), then panel p+1
+        if (p > 0) __syncthreads();                                  // panel p staged by every wave
+        if (p == 2) PANEL_STAMP(3);
+        if (w == 0) {
+            const int bad = panel_factor_lane_rows<PW>(Pc, p, l);
+            if (p == 2) PANEL_STAMP(4);
+            if (bad && l == 0 && sh_bad == 0) sh_bad = bad;          // (only wave 0 writes; panels in order -> the first one sticks)
+        } else if (active && p > 0) {
+            // deferred part of panel p-1: every tile to the right of the one that holds panel p (that one was updated at the end of
+            // the previous round); runs while wave 0 factors
+            update_from(Pq, p / HPT + 1, true);
+        }
+        __syncthreads();                                             // factored panel (L rows 0..63, X rows 64..127) in Pc
+        if (p == 2) PANEL_STAMP(5);
+        if (p == 3) PANEL_STAMP(7);
+        if (active) {
+            const int tp = p / HPT;                                  // tile that holds panel p
+            const int tn = (p + 1) / HPT;                            // tile that holds panel p + 1
+            if (p + 1 < npan) {
+                // the tile with the next panel, now; wave 0 (which has no deferred phase) brings its other tiles up to date as well
+                update_from(Pc, tn, w == 0);
+            }
+            // final values of panel p into my tiles (after the update: with two panels per tile the update above also touched them)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                if (ct == tp && (HPT == 1 || (li / PW) == (p % HPT))) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][ct][r] = Pc[(32 * w + lk + 4 * r) * PSW + (li % PW)];
+                        acc[1][ct][r] = Pc[(32 * w + 16 + lk + 4 * r) * PSW + (li % PW)];
+                    }
+                }
+            }
+            if (p + 1 < npan) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (ct == tn) stage(Pq, p + 1, acc[0][ct], acc[1][ct]);
+            }
+        }
+        if (p == 2) PANEL_STAMP(6);
+    }
+    PANEL_STAMP(2);
+
+    // ---- store: workgroup 0 the lower triangle of A_jj (after everybody has read it), the others their extra rows
+    if (!tall) {
+        __syncthreads();
+        if (tid == 0) {
+            int it = 0, ex = 0;
+            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++it > (1 << 24)) { ex = 1; break; }
+            }
+            sh_expired = ex;
+        }
+        __syncthreads();
+        if (sh_expired) {
+            if (tid == 0) atomicCAS(info, 0, -1);
+            return;
+        }
+        if (rows_diag) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 32 * w + 16 * rt + lk + 4 * r, col = 16 * ct + li;
+                        if (row < nb && col <= row) A[(long)row * lda + col] = acc[rt][ct][r];
+                    }
+        }
+        const int bad = sh_bad;
+        if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, pivot_base + bad);
+    } else if (!rows_diag) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int xr = 32 * (w - 2) + 16 * rt + lk + 4 * r, col = 16 * ct + li;
+                    if (xr < xrows && col < nb) Xg[(long)xr * lda + col] = acc[rt][ct][r];
+                }
     }
 }
 
@@ -954,6 +1231,7 @@ int g_dbg = 0;
 int g_mt_trsm = 0;
 int g_persistent_ob = 0;                                             // gpk_debug_set key 7: 1 = persistent outer-block kernel (slower, see its header)
 int g_left_looking_panels = 1;                                       // gpk_debug_set key 18: 0 = right-looking rank-64 updates also in the pipelined chain
+int g_panel_mfma = 1;                                                // gpk_debug_set key 21: 0 = first-design panel kernel (potf2_tile: two columns per barrier)
 int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
@@ -1193,6 +1471,10 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
         if (g_fused_panel) {
             const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
             const unsigned target = h->panel_loaded + (unsigned)nrb;
+            if (g_panel_mfma)
+                potrf_panel_mfma_kernel<8><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                            (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+            else
             potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                 (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
             GPK_LAUNCH_CHECK(h);                                     // a failed launch issues no tickets: count them only now
@@ -1217,7 +1499,13 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
     return 0;
 }
 
-int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
+static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss,
+                           int pivot_base);
+extern int g_pipeline;
+int g_potrf_pipeline_min_n = 2048, g_potrf_pipeline_max_n = 0;      // gpk_debug_set keys 19 / 20: plain Cholesky pipelined for orders in
+                                                                     // [min, max] (max = 0: off, see gpk_i_potrf)
+
+static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     if (n <= 0) return 0;
     constexpr int OB = 512;
     for (int k0 = 0; k0 < n; k0 += OB) {
@@ -1231,6 +1519,12 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
         }
     }
     return 0;
+}
+
+int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
+    if (g_pipeline && n >= g_potrf_pipeline_min_n && n <= g_potrf_pipeline_max_n && h->num_cu >= 64)
+        return potrf_pipelined(h, nullptr, 0, 0, n, 0, A, lda, nullptr, pivot_base);
+    return potrf_seq(h, A, n, lda, pivot_base);
 }
 
 // ---- SYRK + Cholesky of the Gauss-Newton matrix, pipelined on two CU partitions -------------------------------------------
@@ -1283,9 +1577,9 @@ static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
 }
 
 int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss) {
-    constexpr int OB = 512;
-    const int J = gpk_ceil_div(nc, OB);
+    const int J = gpk_ceil_div(nc, 512);
     h->pipe_tev_used = 0;
+    h->prof_pipelined = 0;
     if (!g_pipeline || J < 3 || nc > g_pipeline_max_n || h->num_cu < 64) {   // small systems: nothing to overlap; large: see above
         if (h->prof) {
             while (h->pipe_tev.size() < 2) { hipEvent_t e; GPK_HIP(h, hipEventCreate(&e)); h->pipe_tev.push_back(e); }
@@ -1296,6 +1590,19 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
         if (d_loss) GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)(nc - 1) * ldh + (nc - 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         return gpk_i_potrf(h, Hb, nc, ldh, 0);
     }
+    GPK_TRY(potrf_pipelined(h, W, ldw, rows, nc, lead, Hb, ldh, d_loss, 0));
+    h->prof_pipelined = 1;
+    return 0;
+}
+
+// W != nullptr: Hb <- chol(W^T W), the product pipelined with the factorisation (Gauss-Newton step).  W == nullptr: Hb holds a
+// symmetric positive definite matrix (lower triangle) and is factored in place -- the same two-partition schedule without the
+// products: left-looking 512-column block updates on the GEMM partition, panel chains on the chain partition.
+static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss,
+                           int pivot_base) {
+    constexpr int OB = 512;
+    const int J = gpk_ceil_div(nc, OB);
+    if (J < 2) return potrf_seq(h, Hb, nc, ldh, pivot_base);
     GPK_TRY(pipe_setup(h, 2 * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
     const hipStream_t main_s = h->stream, G = h->pipe_g, C = h->pipe_c;
     // product of the blocks [jb, je): Hb[jb OB :, jb OB : je OB] = W[:, jb OB :]^T W[:, jb OB : je OB] (tiles above the diagonal skipped)
@@ -1329,8 +1636,10 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
     // sequential (one stream, whole chip) 4.25.
     int pre = g_pipeline_pre < 1 ? 1 : g_pipeline_pre;
     if (pre > J - 1) pre = J - 1;
-    rc = timed_product(main_s, 0, pre);
-    if (rc) return rc;
+    if (W) {
+        rc = timed_product(main_s, 0, pre);
+        if (rc) return rc;
+    }
     PIPE_HIP(hipEventRecord(ev_fork, main_s));
     PIPE_HIP(hipStreamWaitEvent(G, ev_fork, 0));
     PIPE_HIP(hipStreamWaitEvent(C, ev_fork, 0));
@@ -1349,13 +1658,13 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
             if (rc) break;
         }
         PIPE_HIP(hipEventRecord(ev_ready[j], G));
-        if (j + pre < J) {                                           // product of the block `pre` ahead, while the chain of block j runs
+        if (W && j + pre < J) {                                      // product of the block `pre` ahead, while the chain of block j runs
             rc = timed_product(G, j + pre, j + pre + 1);
             if (rc) break;
         }
         h->stream = C;
         PIPE_HIP(hipStreamWaitEvent(C, ev_ready[j], 0));
-        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, j0, g_left_looking_panels != 0);
+        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, pivot_base + j0, g_left_looking_panels != 0);
         if (rc) break;
         PIPE_HIP(hipEventRecord(ev_chain[j], C));
     }
@@ -1366,7 +1675,6 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
     }
     PIPE_HIP(hipStreamWaitEvent(main_s, ev_chain[J - 1], 0));       // (everything on G precedes ev_ready[J-1], which C waited for)
 #undef PIPE_HIP
-    h->prof_pipelined = 1;
     return 0;
 }
 
@@ -1424,6 +1732,8 @@ extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = 
 extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0; }
 extern "C" int gpk_debug_set_left_looking_panels(int v) { g_left_looking_panels = v; return 0; }
+extern "C" int gpk_debug_set_panel_mfma(int v) { g_panel_mfma = v; return 0; }
+extern "C" int gpk_debug_set_potrf_pipeline(int key, int v) { (key == 19 ? g_potrf_pipeline_min_n : g_potrf_pipeline_max_n) = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
     if (!h) return GPK_ERR_ARG;

@@ -519,6 +519,8 @@ extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
 extern "C" int gpk_debug_set_pipeline_max_n(int v);
 extern "C" int gpk_debug_set_pipeline_pre(int v);
 extern "C" int gpk_debug_set_left_looking_panels(int v);
+extern "C" int gpk_debug_set_potrf_pipeline(int key, int v);
+extern "C" int gpk_debug_set_panel_mfma(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -538,6 +540,8 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 15) { g_stagger = value; return 0; }
     if (key == 17) return gpk_debug_set_pipeline_pre(value);
     if (key == 18) return gpk_debug_set_left_looking_panels(value);
+    if (key == 19 || key == 20) return gpk_debug_set_potrf_pipeline(key, value);
+    if (key == 21) return gpk_debug_set_panel_mfma(value);
     if (key == 16) { g_rev_k = value; return 0; }
     return GPK_ERR_ARG;
 }

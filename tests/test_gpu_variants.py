@@ -24,8 +24,10 @@ VARIANTS = [
     ('right-looking rank-64 updates inside the block columns of the pipelined factorisation', {18: 0}),
     ('pipeline with two pre-fork blocks and a 64-CU chain partition', {17: 2, 13: 64}),
     ('leading-zero products walking K downwards', {16: 1}),
+    ('first-design Cholesky panel kernel (two columns per barrier)', {21: 0}),
+    ('Cholesky of Theta on the two-partition pipeline as well', {20: 100000}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 5000, 16: 0, 17: 1, 18: 1}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 5000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
