@@ -33,6 +33,7 @@ struct gpk_ctx {
     // and the "chain" stream that runs the latency-bound panel kernels -- and the events that order them
     hipStream_t pipe_g = nullptr, pipe_c = nullptr;
     int pipe_chain_cus = 0;
+    bool pipe_unavailable = false;          // creating the CU-masked streams failed once: this handle stays on the one-stream schedule
     std::vector<hipEvent_t> pipe_ev;        // ordering events (timing disabled)
     std::vector<hipEvent_t> pipe_tev;       // timing events around the SYRK launches (only while prof is on)
     int pipe_tev_used = 0;

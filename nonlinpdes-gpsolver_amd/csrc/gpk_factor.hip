@@ -1522,7 +1522,7 @@ static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 }
 
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
-    if (g_pipeline && n >= g_potrf_pipeline_min_n && n <= g_potrf_pipeline_max_n && h->num_cu >= 64)
+    if (g_pipeline && !h->pipe_unavailable && n >= g_potrf_pipeline_min_n && n <= g_potrf_pipeline_max_n && h->num_cu >= 64)
         return potrf_pipelined(h, nullptr, 0, 0, n, 0, A, lda, nullptr, pivot_base);
     return potrf_seq(h, A, n, lda, pivot_base);
 }
@@ -1580,7 +1580,13 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
     const int J = gpk_ceil_div(nc, 512);
     h->pipe_tev_used = 0;
     h->prof_pipelined = 0;
-    if (!g_pipeline || J < 3 || nc > g_pipeline_max_n || h->num_cu < 64) {   // small systems: nothing to overlap; large: see above
+    // (a handle on which the CU-masked streams could not be created -- a runtime or a container that does not allow CU masks --
+    // silently keeps the one-stream schedule: same results, no overlap)
+    if (!h->pipe_unavailable && g_pipeline && J >= 3 && nc <= g_pipeline_max_n && h->num_cu >= 64 && pipe_setup(h, 2 * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0) != 0) {
+        h->pipe_unavailable = true;
+        (void)hipGetLastError();
+    }
+    if (h->pipe_unavailable || !g_pipeline || J < 3 || nc > g_pipeline_max_n || h->num_cu < 64) {   // small systems: nothing to overlap; large: see above
         if (h->prof) {
             while (h->pipe_tev.size() < 2) { hipEvent_t e; GPK_HIP(h, hipEventCreate(&e)); h->pipe_tev.push_back(e); }
             GPK_HIP(h, hipEventRecord(h->pipe_tev[0], h->stream));
