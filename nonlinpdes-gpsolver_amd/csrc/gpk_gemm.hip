@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // compute at the same moments -- and reaches 56-59 TFLOP/s; with a start-time stagger of slot x 1024 cycles it reaches
         // 67 (tools/gemm_tail_probe.py; launches of >= 2 waves de-phase by themselves: 68-70 either way).  Inside the
         // Gauss-Newton step the one-wave launches have K <= 1024 and the stagger changes nothing (per-launch times within 1 %),
-        // so it stays off.  The wave slot id (HW_REG_HW_ID[3:0]) differs between the co-resident workgroups.
+        // and neither do the one-wave, long-K product launches of the pipelined phase (sum of launches 2.70-2.74 ms either way), so it
+        // stays off.  The wave slot id (HW_REG_HW_ID[3:0]) differs between the co-resident workgroups.
         const int slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 0xf;    // size 4, offset 0, register 4 (HW_ID)
         for (int i = 0; i < (slot & 3) * g.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
