@@ -120,6 +120,24 @@ def test_gemm(ctx, ta, tb, m, n, k):
     assert np.max(np.abs(got - want)) <= bound
 
 
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('m,n,k,alpha', [(1000, 64, 448, -1.0), (300, 33, 200, 1.0), (257, 64, 65, -1.0), (4000, 50, 512, -1.0), (640, 64, 64, -1.0)])
+def test_gemm_update_kernels(ctx, ta, tb, m, n, k, alpha):
+    """C <- C +- A B with a tall-and-skinny C: the rank-<=64 one-shot kernel and its chunked form for K <= 512 (ragged K and N)"""
+    rng = np.random.RandomState(m + n + k)
+    A = rng.normal(size=(k, m) if ta else (m, k))
+    B = rng.normal(size=(n, k) if tb else (k, n))
+    Cm = rng.normal(size=(m, n))
+    opA = A.T if ta else A
+    opB = B.T if tb else B
+    want = alpha * opA @ opB + Cm
+    dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+    ctx.gemm(ta, tb, m, n, k, alpha, dA, dB, 1.0, dC)
+    got = dC.download()
+    bound = 1e-13 * (np.abs(opA) @ np.abs(opB) + np.abs(Cm)).max()
+    assert np.max(np.abs(got - want)) <= bound
+
+
 def test_gemm_unaligned_leading_dimension(ctx):
     """odd ld / odd offsets take the scalar-load path"""
     rng = np.random.RandomState(5)
