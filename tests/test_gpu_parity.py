@@ -123,7 +123,8 @@ def test_gemm(ctx, ta, tb, m, n, k):
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k,alpha', [(1000, 64, 448, -1.0), (300, 33, 200, 1.0), (257, 64, 65, -1.0), (4000, 50, 512, -1.0), (640, 64, 64, -1.0)])
 def test_gemm_update_kernels(ctx, ta, tb, m, n, k, alpha):
-    """C <- C +- A B with a tall-and-skinny C: the rank-<=64 one-shot kernel and its chunked form for K <= 512 (ragged K and N)"""
+    """C <- C +- A B with a tall-and-skinny C (ragged K and N): the rank-<=64 one-shot kernel and the shapes of the left-looking
+    updates of the Cholesky chain"""
     rng = np.random.RandomState(m + n + k)
     A = rng.normal(size=(k, m) if ta else (m, k))
     B = rng.normal(size=(n, k) if tb else (k, n))
