@@ -1543,7 +1543,7 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 // The chain of block j runs next to S_{j+1} and the early part of U_{j+1}.  Same flops as the right-looking order (plus the
 // upper triangles of the 512 x 512 diagonal blocks, which are computed and never read).
 int g_pipeline = 1;                                                  // gpk_debug_set key 12: 0 = SYRK, then right-looking Cholesky, on one stream
-int g_pipeline_chain_cus = 32;                                       // gpk_debug_set key 13: CUs of the chain partition (multiple of 8)
+int g_pipeline_chain_cus = 32;                                       // gpk_debug_set key 13: CUs of the chain partition (rounded to a multiple of 32)
 // The partition costs the GEMM side a quarter of the chip, the chain side roughly doubles the time of its rank-64 updates;
 // the overlap pays while the panel chain (~34 us per 64 columns) is comparable to the GEMM work (~n^3): measured 4.24 -> 3.96 ms
 // at n = 4001 (BASELINE config 2) but 35.9 -> 43.8 ms at n = 10001, break-even near n = 5500.
@@ -1551,9 +1551,11 @@ int g_pipeline_pre = 1;                                              // gpk_debu
 int g_pipeline_max_n = 5000;                                         // gpk_debug_set key 14: pipelined only up to this order
 
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
-    int c = (g_pipeline_chain_cus / 8) * 8;
-    if (c < 8) c = 8;
-    if (c > h->num_cu - 8) c = h->num_cu - 8;
+    // multiples of 32: bits 8k .. 8k+7 of the mask are one CU of shader engine k mod 4 on each of the 8 XCDs, so 32 bits take one CU from
+    // every shader engine; other sizes leave the engines uneven (measured: 48 behaves like 32, 80 like 64)
+    int c = ((g_pipeline_chain_cus + 16) / 32) * 32;
+    if (c < 32) c = 32;
+    if (c > h->num_cu - 32) c = h->num_cu - 32;
     if (!h->pipe_g || h->pipe_chain_cus != c) {
         if (h->pipe_g) { GPK_HIP(h, hipStreamSynchronize(h->pipe_g)); GPK_HIP(h, hipStreamDestroy(h->pipe_g)); h->pipe_g = nullptr; }
         if (h->pipe_c) { GPK_HIP(h, hipStreamSynchronize(h->pipe_c)); GPK_HIP(h, hipStreamDestroy(h->pipe_c)); h->pipe_c = nullptr; }

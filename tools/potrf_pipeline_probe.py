@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
 import gpk
 ctx = gpk.Context(0)
 rng = np.random.RandomState(0)
-for n in (4001, 8400, 12000, 21000):
+for n in (6000, 8400, 12000, 16000):
     k = 256
     M = ctx.array(rng.normal(size=(k, n)))
     A0 = ctx.empty(n, n)
@@ -19,15 +19,15 @@ for n in (4001, 8400, 12000, 21000):
     diag = np.array([0.0])
     A_host = None
     ref = None
-    if n <= 4001:
+    if n <= 100:
         A_host = np.tril(A0.download()); A_host = A_host + np.tril(A_host, -1).T + n * np.eye(n)
         ref = np.linalg.cholesky(A_host)
         A0.upload(A_host)
     else:
         # large n: shift the diagonal by uploading a strided column would need the whole matrix; use identity nugget through assemble-free trick
         A_host = A0.download(); A_host[np.arange(n), np.arange(n)] += n; A0.upload(A_host); del A_host
-    for label, keys in (('sequential        ', {20: 0}), ('pipelined c=32 LL ', {20: 100000, 13: 32, 18: 1}), ('pipelined c=32 RL ', {20: 100000, 13: 32, 18: 0}),
-                        ('pipelined c=48 RL ', {20: 100000, 13: 48, 18: 0}), ('pipelined c=64 RL ', {20: 100000, 13: 64, 18: 0}), ('pipelined c=64 LL ', {20: 100000, 13: 64, 18: 1})):
+    for label, keys in (('sequential        ', {20: 0}), ('pipelined c=32 LL ', {20: 100000, 13: 32, 18: 1}), ('pipelined c=48 LL ', {20: 100000, 13: 48, 18: 1}),
+                        ('pipelined c=64 LL ', {20: 100000, 13: 64, 18: 1}), ('pipelined c=80 LL ', {20: 100000, 13: 80, 18: 1}), ('pipelined c=64 RL ', {20: 100000, 13: 64, 18: 0})):
         for kk, v in keys.items():
             ctx.lib.gpk_debug_set(kk, v)
         best = 1e9
