@@ -92,3 +92,22 @@ def test_two_rank_flow_survives_a_one_sided_failure(tmp_path):
     d = json.loads(lines[0])
     assert d['value'] == 42.0 and d['n_gpus'] == 2
     assert 'out of memory (simulated)' in d['sharded_config']['error'] and 'rank 1' in d['sharded_config']['error']
+
+
+def test_flop_models_of_the_roofline_objects():
+    """bench.py divides MODELLED flop counts by measured times: the models must sit between the exact structural count and the
+    dense count, and reproduce the launch count seen in the kernel trace (17 NN GEMM launches per step at config 2)."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module('bench')
+    N, nz = 8400, 4000
+    flops, launches = bench.trsm_dinv_executed_flops(N, nz, 1024)
+    dense = float(N) * N * (nz + 1)
+    exact = (N ** 3 - (N - nz) ** 3) / 3.0                        # sum over columns of (rows below the first non-zero)^2
+    assert launches == 17
+    assert exact <= flops <= 1.03 * exact and flops < 0.62 * dense
+    syrk = bench.syrk_executed_flops(N, nz)
+    assert bench.syrk_pipelined_flops(N, nz) == syrk              # the pipelined launches skip the tiles above the diagonal
+    assert 0.69 * N * (nz + 1) ** 2 < syrk < 0.71 * N * (nz + 1) ** 2
+    f256, l256 = bench.trsm_dinv_executed_flops(N, nz, 256)
+    assert l256 > launches and abs(f256 - flops) < 0.02 * flops   # same work, more (smaller) launches

@@ -51,3 +51,62 @@ def test_argument_errors_are_reported(ctx):
     with pytest.raises(gpk.GpkError):
         ctx._chk(rc)
     assert ctx.lib.gpk_trsm(ctx.h, 0, None, 4, 4, A.ptr, 1, 1) != 0                 # null factor
+
+
+def test_inverted_block_entry_points_degenerate_and_errors(ctx):
+    """gpk_trtri_diag / gpk_trsm_dinv: empty systems are no-ops, a bad block size or aliased operands are refused"""
+    A = ctx.array(np.eye(4) * 2.0)
+    D = ctx.empty(4, 256, ld=256)
+    B = ctx.array(np.ones((4, 3))); X = ctx.empty(4, 3); X.zero()
+    assert ctx.lib.gpk_trtri_diag(ctx.h, A.ptr, 0, A.ld, D.ptr, 256) == 0
+    assert ctx.lib.gpk_trsm_dinv(ctx.h, A.ptr, D.ptr, 256, 0, A.ld, B.ptr, 3, B.ld, X.ptr, X.ld, 0) == 0
+    assert ctx.lib.gpk_trsm_dinv(ctx.h, A.ptr, D.ptr, 256, 4, A.ld, B.ptr, 0, B.ld, X.ptr, X.ld, 0) == 0
+    assert ctx.lib.gpk_trtri_diag(ctx.h, A.ptr, 4, A.ld, D.ptr, 100) != 0           # block size not 256 / 512 / 1024
+    assert ctx.lib.gpk_trsm_dinv(ctx.h, A.ptr, D.ptr, 300, 4, A.ld, B.ptr, 3, B.ld, X.ptr, X.ld, 0) != 0
+    assert ctx.lib.gpk_trsm_dinv(ctx.h, A.ptr, D.ptr, 256, 4, A.ld, B.ptr, 3, B.ld, B.ptr, B.ld, 0) != 0      # X aliases B
+    assert ctx.lib.gpk_trsm_dinv(ctx.h, A.ptr, None, 256, 4, A.ld, B.ptr, 3, B.ld, X.ptr, X.ld, 0) != 0       # null inverses
+    # and the tiny valid case: diag(2) -> X = B / 2
+    assert ctx.lib.gpk_trtri_diag(ctx.h, A.ptr, 4, A.ld, D.ptr, 256) == 0
+    assert ctx.lib.gpk_trsm_dinv(ctx.h, A.ptr, D.ptr, 256, 4, A.ld, B.ptr, 3, B.ld, X.ptr, X.ld, 0) == 0
+    ctx.synchronize()
+    np.testing.assert_allclose(X.download(), np.full((4, 3), 0.5))
+
+
+def test_one_context_alternating_problem_shapes():
+    """The Gauss-Newton step keeps its out-of-place solve buffer in the handle and relies on the part it never writes being zero:
+    steps of problems with different shapes, layouts (reversed / plain) and systems through ONE context must give what each
+    problem gives in a context of its own."""
+    import gpk
+
+    def setup(ctx, Nd, Nb, seed):
+        rng = np.random.RandomState(seed)
+        Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+        f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+        T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-8, 'adaptive')
+        assert ctx.potrf(T) == 0
+        prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0, dinv=256)
+        return prob, ctx.array(rng.normal(size=Nd))
+
+    shapes = [(700, 120, 1), (1100, 90, 2), (700, 120, 1), (640, 64, 3)]
+    want = []
+    for Nd, Nb, seed in shapes[:2] + shapes[3:]:
+        c = gpk.Context(0)
+        prob, z = setup(c, Nd, Nb, seed)
+        for _ in range(2):
+            c.gn_step(prob, z)
+        H, grad = c.gn_hessian_grad(prob, z)                      # plain layout through the same workspace
+        c.gn_step(prob, z)
+        want.append((z.download().copy(), H.copy()))
+        c.close()
+    want = [want[0], want[1], want[0], want[2]]
+    c = gpk.Context(0)
+    probs = [setup(c, Nd, Nb, seed) for Nd, Nb, seed in shapes]
+    for _ in range(2):                                            # interleave the steps of the four problems
+        for prob, z in probs:
+            c.gn_step(prob, z)
+    for (prob, z), (zw, Hw) in zip(probs, want):
+        H, grad = c.gn_hessian_grad(prob, z)
+        c.gn_step(prob, z)
+        np.testing.assert_array_equal(H, Hw)
+        np.testing.assert_array_equal(z.download(), zw)
+    c.close()
