@@ -162,18 +162,23 @@ def stored_pmc_traffic(which='syrk'):
 
 
 class AbortWatch:
-    """N > 1 ranks: a rank that fails in the middle of the secondary (sharded) run cannot tell peers that are blocked
-    inside a collective -- they would sit there until the RCCL timeout and the primary value would be lost.  Every rank
-    therefore polls a key of the rendezvous store from a daemon thread while that run is in flight; the failing rank sets
-    it, and on seeing it rank 0 prints the one JSON line (primary value + the error) and every rank leaves the process
-    without touching the process group again."""
+    """Keeps the primary result alive while the SECONDARY (sharded) run is in flight.
+    * N > 1 ranks: a rank that fails in the middle of that run cannot tell peers that are blocked inside a collective -- they
+      would sit there until the RCCL timeout and the primary value would be lost.  Every rank therefore polls a key of the
+      rendezvous store from a daemon thread; the failing rank sets it, and on seeing it rank 0 prints the one JSON line
+      (primary value + the error) and every rank leaves the process without touching the process group again.
+    * any N: a deadline (GPK_SHARDED_TIMEOUT seconds, default 420; the run takes 10-20 s) -- a hang of the secondary run (a
+      collective that never completes on some fabric) ends the same way instead of taking the whole benchmark with it."""
     KEY = 'gpk_bench_abort'
 
-    def __init__(self, rank, primary_out):
+    def __init__(self, rank, primary_out, use_store=True):
         import threading
-        import torch.distributed as dist
         self.rank, self.out = rank, primary_out
-        self.store = dist.distributed_c10d._get_default_store()
+        self.store = None
+        if use_store:
+            import torch.distributed as dist
+            self.store = dist.distributed_c10d._get_default_store()
+        self.deadline = time.monotonic() + float(os.environ.get('GPK_SHARDED_TIMEOUT', '420'))
         self.done = threading.Event()
         self.lock = threading.Lock()                              # main thread and watcher may both get here: ONE line only
         self.thread = threading.Thread(target=self._poll, daemon=True)
@@ -189,8 +194,16 @@ class AbortWatch:
 
     def _poll(self):
         while not self.done.wait(0.5):
+            if time.monotonic() > self.deadline:
+                msg = f'rank {self.rank}: the sharded run did not finish within its deadline (GPK_SHARDED_TIMEOUT); abandoned'
+                try:
+                    if self.store is not None and not self.store.check([self.KEY]):
+                        self.store.set(self.KEY, msg)
+                except Exception:
+                    pass
+                self._finish(msg)
             try:
-                if self.store.check([self.KEY]):
+                if self.store is not None and self.store.check([self.KEY]):
                     self._finish(self.store.get(self.KEY).decode(errors='replace'))
             except Exception:                                     # store gone: the job is being torn down anyway
                 return
@@ -199,10 +212,11 @@ class AbortWatch:
         """called by the rank that caught the exception; if a peer reported first, its message is the cause (this rank most
         likely only saw the peer's connection close)"""
         try:
-            if self.store.check([self.KEY]):
-                msg = self.store.get(self.KEY).decode(errors='replace')
-            else:
-                self.store.set(self.KEY, msg)
+            if self.store is not None:
+                if self.store.check([self.KEY]):
+                    msg = self.store.get(self.KEY).decode(errors='replace')
+                else:
+                    self.store.set(self.KEY, msg)
         except Exception:
             pass
         self._finish(msg)
@@ -538,7 +552,7 @@ def main():
         from gpk.sharded import Comm
         out = run_single(args, workload, Comm() if world > 1 else None)
         if args.workload == 'auto' and not args.no_sharded_config:
-            watch = AbortWatch(int(os.environ.get('RANK', '0')), out) if use_pg else None
+            watch = AbortWatch(int(os.environ.get('RANK', '0')), out, use_store=use_pg)
             try:                                                  # the value above must survive a failure of the secondary run
                 sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
                 if out is not None and sh is not None:
@@ -546,12 +560,11 @@ def main():
                                                                  'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
                 msg = f'{type(e).__name__}: {e}'
-                if watch is not None:
+                if use_pg:
                     watch.fail(f"rank {os.environ.get('RANK', '0')}: {msg}")      # does not return (peers may be blocked in a collective)
                 if out is not None:
                     out['sharded_config'] = {'error': msg}
-            if watch is not None:
-                watch.stop()
+            watch.stop()
     if use_pg:
         import torch.distributed as dist
         dist.barrier()

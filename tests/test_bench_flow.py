@@ -111,3 +111,29 @@ def test_flop_models_of_the_roofline_objects():
     assert 0.69 * N * (nz + 1) ** 2 < syrk < 0.71 * N * (nz + 1) ** 2
     f256, l256 = bench.trsm_dinv_executed_flops(N, nz, 256)
     assert l256 > launches and abs(f256 - flops) < 0.02 * flops   # same work, more (smaller) launches
+
+
+def test_hanging_sharded_run_is_abandoned_at_the_deadline(tmp_path):
+    """One process, no process group: the secondary run hangs; at the deadline the primary line is printed with the reason and
+    the process exits 0."""
+    script = tmp_path / 'drive.py'
+    script.write_text(textwrap.dedent(f'''
+        import os, sys, time
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'nonlinpdes-gpsolver_amd'))
+        import bench
+        bench.run_single = lambda args, workload, comm=None: {{'metric': 'm', 'value': 7.0, 'n_gpus': 1, 'steps': args.steps}}
+        def hang(args, workload, steps=None, warmup=None):
+            time.sleep(3600)
+        bench.run_sharded = hang
+        sys.argv = ['bench.py', '--steps', '4', '--warmup', '1']
+        bench.main()
+    '''))
+    env = dict(os.environ, GPK_SHARDED_TIMEOUT='2')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'GPK_FORCE_PG'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['value'] == 7.0 and 'deadline' in d['sharded_config']['error']
