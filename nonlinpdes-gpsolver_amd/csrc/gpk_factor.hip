@@ -5,12 +5,18 @@
 // src/InverseProblems.py:118-119,145-146,190,195).  The reference calls a GENERAL LU solve on the lower-triangular
 // L each time; here L is used as what it is.
 //
-// Structure: all O(n^3) work is delegated to gpk_i_gemm (MFMA); only 64-wide diagonal blocks are handled by the
-// substitution kernels below (true substitution, no explicit inverses: cond(Theta) ~ 1e13+ leaves no slack).
-//   potrf(A)      = two-level right-looking (see gpk_i_potrf)
-//   trsm_left(L)  = solve with L11; B2 -= L21 X1; solve with L22          (transposed: mirror image)
-//   trsm_right_lt = X1 <- X1 L11^{-T}; X2 -= X1 L21^T; X2 <- X2 L22^{-T}
-// The recursion splits at multiples of 64/128 so that sub-blocks stay 16-byte aligned for the GEMM's vector loads.
+// Structure: all O(n^3) work is delegated to gpk_i_gemm (MFMA); the diagonal blocks are handled by the kernels below.
+//   potrf(A)          = two-level right-looking (gpk_i_potrf): 512-column blocks, inside a block one fused panel kernel per 64
+//                       columns (potrf_panel_mfma_kernel, round 2; potrf_panel_kernel, round 1) + rank-64 updates
+//   syrk_potrf(W)     = chol(W^T W) of the Gauss-Newton step, product and factorisation pipelined by 512-column blocks on two
+//                       CU-mask partitions (gpk_i_syrk_potrf / potrf_pipelined)
+//   trsm_left(L)      = solve with L11; B2 -= L21 X1; solve with L22 (transposed: mirror image); leaves: 256-row strip kernel
+//   trsm_left_dinv(L) = the same recursion with leaves X_k = inv(L_kk) B_k: GEMMs only, for a factor that is used many times
+//                       (the inverses of its diagonal BLOCKS come from gpk_i_trtri_diag, by substitution; accuracy: see there)
+//   trsm_right_lt     = X1 <- X1 L11^{-T}; X2 -= X1 L21^T; X2 <- X2 L22^{-T}
+//   trsv              = single-vector solves in one launch, workgroups chained through flags (trsv_fused_kernel)
+// True substitution everywhere except trsm_left_dinv.  The recursions split at multiples of 64/128/256 so that sub-blocks stay
+// 16-byte aligned for the GEMM's vector loads.
 #include "gpk_common.h"
 #include <type_traits>
 
