@@ -240,7 +240,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     Dims d;
     GPK_TRY(check_prob(h, p, d));
     const int nz = d.nz;
-    const int rev = (p->system == GPK_GN_ELLIPTIC) ? 1 : 0;
+    // reversed column order (leading-zero layout): unknown u's column of A(z) is zero above row u for the elliptic system (rows t and
+    // N_d + t) and for its relaxed form (unknowns [v; w]: rows t resp. N_d + t of the Theta block, penalty rows at the bottom)
+    const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1 : 0;
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     double* d_loss = h->d_scalars;
