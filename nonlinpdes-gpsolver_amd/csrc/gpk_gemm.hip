@@ -514,6 +514,7 @@ extern "C" int gpk_debug_set_fused_trsv(int v);
 extern "C" int gpk_debug_set_fused_panel(int v);
 extern "C" int gpk_debug_set_persistent_ob(int v);
 extern "C" int gpk_debug_set_use_dinv(int v);
+extern "C" int gpk_debug_set_eikonal_lz(int v);
 extern "C" int gpk_debug_set_probe_chain_cus(int v);
 extern "C" int gpk_debug_set_pipeline(int v);
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
@@ -534,6 +535,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 9) { g_gemm_extra_lds = value; return 0; }
     if (key == 6) { g_supertile = value; return 0; }
     if (key == 10) return gpk_debug_set_use_dinv(value);
+    if (key == 23) return gpk_debug_set_eikonal_lz(value);
     if (key == 11) return gpk_debug_set_probe_chain_cus(value);
     if (key == 12) return gpk_debug_set_pipeline(value);
     if (key == 13) return gpk_debug_set_pipeline_chain_cus(value);

@@ -50,12 +50,19 @@ struct BuildArgs {
     double p0, p1, lam;
     const double* f; const double* gb; const double* data; const double* z;
     double* S; long lds; int fcol; int write_A;
-    int rev;           // store unknown j in column nz-1-j (gn_step of the elliptic system: leading-zero structure)
+    int rev;           // leading-zero layout of gn_step: unknown j is stored in column nz-1-pos(j), and that column of A(z) is zero above
+                       // row pos(j).  1: pos(j) = j (elliptic systems).  2: Eikonal, unknown groups [v0 | v1 | v2] taken in the
+                       // order v1, v2, v0: their first non-zeros sit in rows t, N_d + t, 3 N_d + t >= pos
     int nz;
 };
 
+// position of unknown j in the staircase order (see BuildArgs::rev)
+__host__ __device__ __forceinline__ int stair_pos(int rev, int Nd, int j) {
+    return rev == 2 ? ((j / Nd + 2) % 3) * Nd + j % Nd : j;
+}
+
 __device__ __forceinline__ void putA(const BuildArgs& a, int r, int c, double v) {
-    if (a.write_A) a.S[(long)r * a.lds + (a.rev ? a.nz - 1 - c : c)] = v;
+    if (a.write_A) a.S[(long)r * a.lds + (a.rev ? a.nz - 1 - stair_pos(a.rev, a.Nd, c) : c)] = v;
 }
 __device__ __forceinline__ void putF(const BuildArgs& a, int r, double v) { a.S[(long)r * a.lds + a.fcol] = v; }
 
@@ -135,15 +142,15 @@ __global__ void axpy_kernel(int n, double alpha, const double* __restrict__ x, d
     if (i < n) y[i] += alpha * x[i];
 }
 
-// y[j] += alpha * x[n-1-j]
-__global__ void axpy_rev_kernel(int n, double alpha, const double* __restrict__ x, double* __restrict__ y) {
+// y[j] += alpha * x[n-1-pos(j)]  (back from the staircase order of gn_step to the natural order of the unknowns)
+__global__ void axpy_rev_kernel(int n, double alpha, const double* __restrict__ x, double* __restrict__ y, int rev, int Nd) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] += alpha * x[n - 1 - i];
+    if (i < n) y[i] += alpha * x[n - 1 - stair_pos(rev, Nd, i)];
 }
 
-__global__ void reverse_copy_kernel(int n, const double* __restrict__ x, double* __restrict__ y) {
+__global__ void reverse_copy_kernel(int n, const double* __restrict__ x, double* __restrict__ y, int rev, int Nd) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) y[i] = x[n - 1 - i];
+    if (i < n) y[i] = x[n - 1 - stair_pos(rev, Nd, i)];
 }
 
 __global__ void scale_kernel(int n, double alpha, double* __restrict__ x) {
@@ -172,6 +179,7 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
 }
 
 int g_use_dinv = 1;                  // gpk_debug_set key 10: 0 = substitution strips even when the inverses are supplied
+int g_eikonal_lz = 1;                // gpk_debug_set key 23: 0 = dense schedule for the Eikonal system
 
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } while (0)
 
@@ -242,7 +250,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     const int nz = d.nz;
     // reversed column order (leading-zero layout): unknown u's column of A(z) is zero above row u for the elliptic system (rows t and
     // N_d + t) and for its relaxed form (unknowns [v; w]: rows t resp. N_d + t of the Theta block, penalty rows at the bottom)
-    const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1 : 0;
+    // Eikonal: the same after regrouping the unknowns (BuildArgs::rev = 2).  Burgers (three columns start in every row t: a
+    // staircase of slope 1/3) and Darcy (two factors with different column supports) run the dense schedule.
+    const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1 : (p->system == GPK_GN_EIKONAL && g_eikonal_lz) ? 2 : 0;
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     double* d_loss = h->d_scalars;
@@ -256,8 +266,8 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     GPK_HIP(h, hipMemcpyAsync(dl, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, dl));
     if (rev) {
-        reverse_copy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, dl, delta);
-        axpy_rev_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, dl, z);
+        reverse_copy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, dl, delta, rev, p->Nd);
+        axpy_rev_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, dl, z, rev, p->Nd);
     } else {
         axpy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, delta, z);
     }
@@ -350,3 +360,4 @@ extern "C" int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* p, const d
 }
 
 extern "C" int gpk_debug_set_use_dinv(int v) { g_use_dinv = v; return 0; }
+extern "C" int gpk_debug_set_eikonal_lz(int v) { g_eikonal_lz = v; return 0; }

@@ -80,3 +80,40 @@ def test_latency_probes_run():
           'dep global (1 line) %.1f, dep global (16 lines) %.1f' % tuple(vals))
     assert all(0.5 < v < 5000 for v in vals)
     ctx.close()
+
+
+def test_eikonal_leading_zero_layout_agrees_with_dense_schedule():
+    """Eikonal system: gn_step regroups the unknowns (v1, v2, v0) so that A(z) has the staircase shape the elliptic system has and
+    skips the structural zeros; gpk_debug_set(23, 0) runs the dense schedule.  Same operation -> same iterates, and both agree with
+    the oracle."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(11)
+    Nd, Nb, eps = 700, 120, 0.1                                  # N = 2920, n_z = 2100: several inverted blocks, 5 pipeline blocks
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = np.ones(Nd); g = np.zeros(Nb)
+    T, _ = ctx.assemble('Eikonal', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+    assert ctx.potrf(T) == 0
+    L = np.tril(T.download())
+    z0 = np.zeros(3 * Nd)
+    out = {}
+    try:
+        for mode in (1, 0):
+            ctx.lib.gpk_debug_set(23, mode)
+            prob = gpk.GNProblem(ctx, 'Eikonal', Nd, Nb, f, g, T, p0=eps)
+            z = ctx.array(z0)
+            hist = []
+            for _ in range(4):
+                loss, info = ctx.gn_step(prob, z)
+                assert info == 0
+                hist.append(loss)
+            hist.append(ctx.gn_loss(prob, z))
+            out[mode] = (z.download().copy(), np.array(hist))
+    finally:
+        ctx.lib.gpk_debug_set(23, 1)
+    assert np.max(np.abs(out[1][0] - out[0][0])) <= 1e-9 * np.max(np.abs(out[0][0]))
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-8)
+    sol_ref, hist_ref = O.gn_method(O.EikonalSystem(eps, f, g), [L], z0, 4, 1)
+    assert np.linalg.norm(out[1][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
+    np.testing.assert_allclose(out[1][1], hist_ref, rtol=1e-6)
+    ctx.close()
