@@ -42,6 +42,8 @@ struct gpk_ctx {
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
+    int lead_div = 1;               // slope of the leading-zero staircase while a Gauss-Newton step is being issued: column c of the
+                                    // right-hand side is zero above row (lead-1-c) / lead_div (1: elliptic, Eikonal; 3: Burgers)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // column-group streams of the multi-RHS triangular solve
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // per-phase HIP-event timing of gpk_gn_step (bench.py roofline): 0 TRSM, 1 SYRK launch, 2 POTRF, 3 TRSV+update

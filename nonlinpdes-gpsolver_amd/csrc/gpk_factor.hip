@@ -1294,7 +1294,8 @@ int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, d
 // that contiguous range (rounded down to 64 columns to keep tiles and vector loads aligned).  Columns >= lead are dense.
 int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B, int nrhs, int ldb, int lead, int row0) {
     if (n <= 0 || nrhs <= 0) return 0;
-    int clo = lead - (row0 + n);
+    const int sd = h->lead_div > 0 ? h->lead_div : 1;                // staircase slope 1/sd: column c is zero above row (lead-1-c)/sd
+    int clo = lead - sd * (row0 + n);
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
     if (g_strip && n <= SB && (n & 15) == 0) {
@@ -1311,10 +1312,10 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
     const double* L21 = L + (long)n1 * ldl;
     double* B2 = B + (long)n1 * ldb;
     GPK_TRY(gpk_i_trsm_left_lz(h, L, n1, ldl, B, nrhs, ldb, lead, row0));
-    int c1 = lead - (row0 + n1);                                     // X[rows of part 1] is zero left of this column
+    int c1 = lead - sd * (row0 + n1);                                // X[rows of part 1] is zero left of this column
     c1 = c1 > 0 ? (c1 / NB) * NB : 0;
-    if (c1 < nrhs) {                                                 // X1[k][c] is zero for row0 + k < lead-1-c: late K start per tile
-        const int lz = lead - row0 - c1;
+    if (c1 < nrhs) {                                                 // X1[k][c] is zero for row0 + k < (lead-1-c)/sd: late K start per tile
+        const int lz = lead - sd * row0 - c1;
         GPK_TRY(gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, B + c1, ldb, 1.0, B2 + c1, ldb, false, lz > 0 ? lz : 0));
     }
     GPK_TRY(gpk_i_trsm_left_lz(h, L21 + n1, n2, ldl, B2, nrhs, ldb, lead, row0 + n1));
@@ -1360,11 +1361,12 @@ int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv
 int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int db, int n, int ldl, double* B, int ldb,
                          double* X, int ldx, int nrhs, int lead, int row0) {
     if (n <= 0 || nrhs <= 0) return 0;
-    int clo = lead - (row0 + n);                                     // (lead = 0: dense right-hand sides)
+    const int sd = h->lead_div > 0 ? h->lead_div : 1;                // staircase slope 1/sd: column c is zero above row (lead-1-c)/sd
+    int clo = lead - sd * (row0 + n);                                // (lead = 0: dense right-hand sides)
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
     if (n <= db) {
-        const int lz = lead - row0 - clo;
+        const int lz = lead - sd * row0 - clo;
         return gpk_i_gemm(h, false, false, n, nrhs - clo, n, 1.0, Dinv + (long)row0 * db, db, B + clo, ldb, 0.0, X + clo, ldx,
                           false, lz > 0 ? lz : 0, true);
     }
@@ -1373,10 +1375,10 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
     const int n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     GPK_TRY(gpk_i_trsm_left_dinv(h, L, Dinv, db, n1, ldl, B, ldb, X, ldx, nrhs, lead, row0));
-    int c1 = lead - (row0 + n1);                                     // X[rows of part 1] is zero left of this column
+    int c1 = lead - sd * (row0 + n1);                                // X[rows of part 1] is zero left of this column
     c1 = c1 > 0 ? (c1 / NB) * NB : 0;
     if (c1 < nrhs) {
-        const int lz = lead - row0 - c1;
+        const int lz = lead - sd * row0 - c1;
         GPK_TRY(gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, X + c1, ldx, 1.0, B + (long)n1 * ldb + c1, ldb,
                            false, lz > 0 ? lz : 0));
     }

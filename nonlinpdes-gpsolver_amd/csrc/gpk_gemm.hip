@@ -38,6 +38,7 @@ struct GemmArgs {
     const double* B; long ldb;
     double* C; long ldc;
     int lower_only;
+    int lead_div;      // ... or, with a staircase of slope 1/lead_div, for k < (lead-1-n) / lead_div (gpk_ctx::lead_div)
     int lead;          // operand B (stored [k][n]) has column n zero for k < lead-1-n: the tile with columns [n0, n0+BN)
                        // gets no contribution from k < lead - (n0 + BN), so its K loop starts there.  (SYRK S^T S,
                        // lower tiles: the A tile's columns are further right, i.e. non-zero even earlier.)
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // zeros extra), so that the 32 tiles walk K in step and share operand slabs in L2
         const int nlast = g.nsuper > 0 ? min((tn / SG_W) * SG_W + SG_W - 1, g.ntn - 1) * BN : n0;
         const int z = g.lead - (nlast + BN);
-        kt0 = z > 0 ? z / BK : 0;
+        kt0 = z > 0 ? (z / g.lead_div) / BK : 0;
         if (kt0 > nk) kt0 = nk;
     }
     auto compute = [&](int buf) {
@@ -476,7 +477,7 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.ntiles = g.lower_only ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
     g.nsuper = 0;
     int nblocks = g.ntiles;
-    if (g.lower_only && g.lead > 0 && g_supertile) {
+    if (g.lower_only && g.lead > 0 && g_supertile && g.lead_div == 1) {
         const int T = g.ntm, ncg = gpk_ceil_div(T, SG_W);
         for (int cg = 0; cg < ncg; ++cg) g.nsuper += gpk_ceil_div(T - cg * SG_W, SG_H);
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
@@ -559,6 +560,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
     g.lower_only = lower_only ? 1 : 0;
     g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
+    g.lead_div = h->lead_div > 0 ? h->lead_div : 1;
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.stagger = g_stagger;

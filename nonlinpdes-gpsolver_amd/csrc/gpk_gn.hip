@@ -52,13 +52,15 @@ struct BuildArgs {
     double* S; long lds; int fcol; int write_A;
     int rev;           // leading-zero layout of gn_step: unknown j is stored in column nz-1-pos(j), and that column of A(z) is zero above
                        // row pos(j).  1: pos(j) = j (elliptic systems).  2: Eikonal, unknown groups [v0 | v1 | v2] taken in the
-                       // order v1, v2, v0: their first non-zeros sit in rows t, N_d + t, 3 N_d + t >= pos
+                       // order v1, v2, v0: their first non-zeros sit in rows t, N_d + t, 3 N_d + t >= pos.  3: Burgers, the three
+                       // unknowns of point t (columns t, N_d + t, 2 N_d + t all start in row t) interleaved: pos(j) = 3t + group,
+                       // a staircase of slope 1/3 (column zero above row pos/3; gpk_ctx::lead_div = 3)
     int nz;
 };
 
 // position of unknown j in the staircase order (see BuildArgs::rev)
 __host__ __device__ __forceinline__ int stair_pos(int rev, int Nd, int j) {
-    return rev == 2 ? ((j / Nd + 2) % 3) * Nd + j % Nd : j;
+    return rev == 2 ? ((j / Nd + 2) % 3) * Nd + j % Nd : rev == 3 ? 3 * (j % Nd) + j / Nd : j;
 }
 
 __device__ __forceinline__ void putA(const BuildArgs& a, int r, int c, double v) {
@@ -179,7 +181,7 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
 }
 
 int g_use_dinv = 1;                  // gpk_debug_set key 10: 0 = substitution strips even when the inverses are supplied
-int g_eikonal_lz = 1;                // gpk_debug_set key 23: 0 = dense schedule for the Eikonal system
+int g_eikonal_lz = 1;                // gpk_debug_set key 23: 0 = dense schedule for the Eikonal and Burgers systems
 
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } while (0)
 
@@ -250,9 +252,14 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     const int nz = d.nz;
     // reversed column order (leading-zero layout): unknown u's column of A(z) is zero above row u for the elliptic system (rows t and
     // N_d + t) and for its relaxed form (unknowns [v; w]: rows t resp. N_d + t of the Theta block, penalty rows at the bottom)
-    // Eikonal: the same after regrouping the unknowns (BuildArgs::rev = 2).  Burgers (three columns start in every row t: a
-    // staircase of slope 1/3) and Darcy (two factors with different column supports) run the dense schedule.
-    const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1 : (p->system == GPK_GN_EIKONAL && g_eikonal_lz) ? 2 : 0;
+    // Eikonal: the same after regrouping the unknowns (BuildArgs::rev = 2).  Burgers: the three columns of point t all start in row
+    // t -- interleaved they form a staircase of slope 1/3 (rev = 3).  Darcy (two factors with different column supports) runs the
+    // dense schedule.
+    const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1
+                  : (p->system == GPK_GN_EIKONAL && g_eikonal_lz) ? 2 : (p->system == GPK_GN_BURGERS && g_eikonal_lz) ? 3 : 0;
+    struct SlopeGuard {                                              // the staircase slope is a property of this step's right-hand sides
+        gpk_handle h; explicit SlopeGuard(gpk_handle hh, int s) : h(hh) { h->lead_div = s; } ~SlopeGuard() { h->lead_div = 1; }
+    } slope_guard(h, rev == 3 ? 3 : 1);
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     double* d_loss = h->d_scalars;

@@ -117,3 +117,40 @@ def test_eikonal_leading_zero_layout_agrees_with_dense_schedule():
     assert np.linalg.norm(out[1][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
     np.testing.assert_allclose(out[1][1], hist_ref, rtol=1e-6)
     ctx.close()
+
+
+def test_burgers_leading_zero_layout_agrees_with_dense_schedule():
+    """Burgers system: the three unknowns of a collocation point all enter A(z) first in row t; gn_step interleaves them (3t + group),
+    which gives a staircase of slope 1/3, and skips the zeros above it; gpk_debug_set(23, 0) runs the dense schedule."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(12)
+    Nd, Nb = 650, 99                                             # N = 2699, n_z = 1950 (ragged everywhere)
+    Xd = np.stack([rng.uniform(0, 1, Nd), rng.uniform(-1, 1, Nd)], axis=1)
+    Xb = np.stack([rng.uniform(0, 1, Nb), rng.uniform(-1, 1, Nb)], axis=1)
+    f = np.zeros(Nd); g = -np.sin(np.pi * Xb[:, 1]) * (rng.uniform(size=Nb) < 0.4)
+    T, _ = ctx.assemble('Burgers', 'anisotropic_Gaussian', [0.3, 0.05], Xd, Xb, 1e-5, 'adaptive')
+    assert ctx.potrf(T) == 0
+    L = np.tril(T.download())
+    z0 = rng.normal(size=3 * Nd)
+    out = {}
+    try:
+        for mode in (1, 0):
+            ctx.lib.gpk_debug_set(23, mode)
+            prob = gpk.GNProblem(ctx, 'Burgers', Nd, Nb, f, g, T, p0=1.0, p1=0.02)
+            z = ctx.array(z0)
+            hist = []
+            for _ in range(2):                                   # (from a random start the iteration amplifies rounding differences quickly)
+                loss, info = ctx.gn_step(prob, z)
+                assert info == 0
+                hist.append(loss)
+            hist.append(ctx.gn_loss(prob, z))
+            out[mode] = (z.download().copy(), np.array(hist))
+    finally:
+        ctx.lib.gpk_debug_set(23, 1)
+    assert np.linalg.norm(out[1][0] - out[0][0]) <= 1e-8 * np.linalg.norm(out[0][0])
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-6)   # (this start diverges: losses grow, rounding differences with them)
+    sol_ref, hist_ref = O.gn_method(O.BurgersSystem(1.0, 0.02, f, g), [L], z0, 2, 1)
+    assert np.linalg.norm(out[1][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
+    np.testing.assert_allclose(out[1][1], hist_ref, rtol=1e-6)
+    ctx.close()
