@@ -39,6 +39,14 @@ struct gpk_ctx {
     int pipe_tev_used = 0;
     double prof_syrk_ms = 0;                // accumulated duration of the SYRK launches on the GEMM stream (pipelined mode)
     int prof_pipelined = 0;
+    // split-K GEMM launches (gpk_gemm.hip, GemmArgs::splitk): requested chunk count for the NEXT gpk_i_gemm calls (0/1 = off; set and
+    // cleared by the caller around its launches), the partial-sum workspace and the per-tile arrival counters.  One workspace: only
+    // one stream at a time may issue split launches (the GEMM stream of the pipeline does)
+    int splitk_req = 0;
+    double* d_splitk_ws = nullptr;
+    size_t splitk_ws_cap = 0;       // bytes
+    unsigned* d_splitk_cnt = nullptr;
+    int splitk_cnt_cap = 0;         // counters
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
@@ -75,7 +83,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
                const double* B, int ldb, double beta, double* C, int ldc, bool lower_only, int lead = 0, bool tri_a = false,
                bool skip_upper = false);
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base);               // info -> h->d_info
-int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base, bool left_looking = false);
+int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base, bool left_looking = false,
+                      void* ev_wait_p1 = nullptr, void* ev_rec_pre = nullptr);   // (hipEvent_t; see gpk_factor.hip)
 // Hb <- chol(W^T W) (lower, nc x nc; W is rows x nc with the leading-zero shape `lead` of gpk_i_gemm), the product and the
 // factorisation pipelined by 512-column blocks on two CU partitions (gpk_factor.hip); d_loss (device, may be null) receives
 // the unfactored last diagonal entry (W^T W)[nc-1][nc-1]
@@ -90,6 +99,7 @@ int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl
 int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db);
 int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int db, int n, int ldl, double* B, int ldb,
                          double* X, int ldx, int nrhs, int lead, int row0);
+int gpk_i_splitk_reserve(gpk_handle h);                                                 // workspace + counters of the split-K launches
 int gpk_i_workspace(gpk_handle h, size_t bytes, double** out);                          // handle-owned scratch, grown on demand
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);
 int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x);   // x contiguous

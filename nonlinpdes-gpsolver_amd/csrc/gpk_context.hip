@@ -54,6 +54,8 @@ extern "C" int gpk_destroy(gpk_handle h) {
     if (h->d_obflags) (void)hipFree(h->d_obflags);
     if (h->d_pts) (void)hipFree(h->d_pts);
     if (h->d_work) (void)hipFree(h->d_work);
+    if (h->d_splitk_ws) (void)hipFree(h->d_splitk_ws);
+    if (h->d_splitk_cnt) (void)hipFree(h->d_splitk_cnt);
     for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->pipe_tev) (void)hipEventDestroy(e);
     if (h->pipe_g) (void)hipStreamDestroy(h->pipe_g);
@@ -204,6 +206,18 @@ int gpk_i_ensure_points(gpk_handle h, size_t doubles) {
     h->d_pts = nullptr; h->pts_cap = 0;
     GPK_HIP(h, hipMalloc((void**)&h->d_pts, doubles * sizeof(double)));
     h->pts_cap = doubles;
+    return 0;
+}
+
+int gpk_i_splitk_reserve(gpk_handle h) {
+    if (h->d_splitk_ws) return 0;
+    constexpr size_t WS = (size_t)64 << 20;
+    constexpr int NCNT = 16384;
+    GPK_HIP(h, hipMalloc(&h->d_splitk_cnt, NCNT * sizeof(unsigned)));
+    GPK_HIP(h, hipMemset(h->d_splitk_cnt, 0, NCNT * sizeof(unsigned)));
+    h->splitk_cnt_cap = NCNT;
+    GPK_HIP(h, hipMalloc(&h->d_splitk_ws, WS));
+    h->splitk_ws_cap = WS;
     return 0;
 }
 

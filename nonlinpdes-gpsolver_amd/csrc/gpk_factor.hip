@@ -1452,21 +1452,28 @@ int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X
 // Factor a tall block column: D = A[0:ob, 0:ob] is replaced by its Cholesky factor and the rows below by A[ob:, 0:ob] D^{-T}
 // (64-column panel kernel + rank-64 update of the remaining columns, for all nrows rows).  The building block of both
 // the single-GPU factorisation below and the panel-sharded multi-GPU one (gpk/sharded.py, the owner's share of a step).
-int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base, bool left_looking) {
+int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int pivot_base, bool left_looking, void* ev_wait_p1, void* ev_rec_pre) {
+    // ev_wait_p1 (pipeline): the columns from 64 on become valid only with this event -- waited for before the second panel;
+    // ev_rec_pre: recorded once every panel but the last has been factored (the pipeline starts the next block's update with those)
     if (ob <= 0 || nrows < ob) return 0;
+    const int npan = gpk_ceil_div(ob, NB);
     if (g_persistent_ob) {
+        if (ev_wait_p1) GPK_HIP(h, hipStreamWaitEvent(h->stream, (hipEvent_t)ev_wait_p1, 0));
         if (++h->ob_epoch == 0x7fffffff) {
             GPK_HIP(h, hipMemsetAsync(h->d_obflags, 0, 64 * sizeof(int), h->stream));
             h->ob_epoch = 1;
         }
         potrf_ob_kernel<<<gpk_ceil_div(nrows, NB), 256, 0, h->stream>>>(A, lda, nrows, ob, h->d_obflags, h->ob_epoch, h->d_info, pivot_base, g_dbg);
         GPK_LAUNCH_CHECK(h);
+        if (ev_rec_pre) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));
         return 0;
     }
     for (int j0 = 0; j0 < ob; j0 += NB) {
         const int nb = (ob - j0 < NB) ? ob - j0 : NB;
         double* Ajj = A + (long)j0 * lda + j0;
         const int below = nrows - (j0 + nb);
+        // (left-looking: the other columns are first touched by the second panel's update; right-looking: by the first panel's)
+        if (ev_wait_p1 && j0 == (left_looking ? NB : 0)) GPK_HIP(h, hipStreamWaitEvent(h->stream, (hipEvent_t)ev_wait_p1, 0));
         if (left_looking && j0 > 0) {
             // LEFT-looking inside the block column (used when the chain runs on the small CU partition of the pipeline): the
             // 64 columns of this panel receive the contributions of all earlier panels of the block in one product with K = j0
@@ -1474,6 +1481,10 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             // 7 x rows/32 workgroups, which a 32-CU partition works off in several rounds: 20-30 us instead of 9).  Same flops.
             // On the whole chip the right-looking form is faster (the long-K product on ~110 workgroups is latency-bound:
             // 4.42 vs 4.25 ms for the phase), so it remains the default everywhere else.
+            // (Tried in round 2: the contributions of the panels up to p-2 on a SECOND stream of the same partition, next to panel
+            // p-1's kernel, so that only a rank-64 update stays between two panel kernels.  Not adoptable: the mere existence of one
+            // more stream on the handle -- CU-masked or plain, used or not -- made EVERY kernel of the step slower, the solve
+            // phase included (7.2 -> 9.1 ms per step; single launches +40 %..+350 %).)
             GPK_TRY(gpk_i_gemm(h, false, true, nrows - j0, nb, j0, -1.0, A + (long)j0 * lda, lda, A + (long)j0 * lda, lda, 1.0, Ajj, lda, false));
         }
         if (g_fused_panel) {
@@ -1492,6 +1503,7 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             if (below > 0)
                 trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, g_dbg);
         }
+        if (ev_rec_pre && j0 / NB == npan - 2) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));   // (this panel's columns are final)
         if (below > 0 && !left_looking) {
             double* Abj = A + (long)(j0 + nb) * lda + j0;
             const int pc = ob - (j0 + nb);                           // remaining columns of this block column
@@ -1556,7 +1568,20 @@ int g_pipeline_chain_cus = 32;                                       // gpk_debu
 // the overlap pays while the panel chain (~34 us per 64 columns) is comparable to the GEMM work (~n^3): measured 4.24 -> 3.96 ms
 // at n = 4001 (BASELINE config 2) but 35.9 -> 43.8 ms at n = 10001, break-even near n = 5500.
 int g_pipeline_pre = 1;                                              // gpk_debug_set key 17: blocks of the product computed before the fork
+int g_pipeline_lookahead = 0;                                        // gpk_debug_set key 26: 0 = block j's update with block j-1 as ONE product after the chain of j-1
+int g_pipeline_units = 1000;                                          // gpk_debug_set key 24: workgroups aimed at per product launch of the pipeline (split-K; 0 = no split).  Measured at config 2, phase time: 0 / 1000 / 1500 / 2000 / 3000 -> 3.85 / 3.57 / 3.58 / 3.60 / 3.62 ms
 int g_pipeline_max_n = 5000;                                         // gpk_debug_set key 14: pipelined only up to this order
+
+// Block columns of the pipelined factorisation: a first block of g_pipeline_w0 columns (the chain can only start once its product is
+// there), then blocks of g_pipeline_ob columns; widths are multiples of the panel width, at most 512.
+int g_pipeline_w0 = 512, g_pipeline_ob = 512;                        // gpk_debug_set keys 28 / 29
+static std::vector<int> pipe_blocks(int nc) {
+    auto norm = [](int w) { w = (w / NB) * NB; return w < NB ? NB : (w > 512 ? 512 : w); };
+    std::vector<int> b{0};
+    int w = norm(g_pipeline_w0);
+    while (b.back() < nc) { b.push_back(b.back() + w < nc ? b.back() + w : nc); w = norm(g_pipeline_ob); }
+    return b;
+}
 
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
     // multiples of 32: bits 8k .. 8k+7 of the mask are one CU of shader engine k mod 4 on each of the 8 XCDs, so 32 bits take one CU from
@@ -1573,6 +1598,7 @@ static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
         GPK_HIP(h, hipExtStreamCreateWithCUMask(&h->pipe_g, 8, mg));
         h->pipe_chain_cus = c;
     }
+    GPK_TRY(gpk_i_splitk_reserve(h));                               // split-K products of the GEMM stream (gpk_gemm.hip)
     while (h->pipe_ev.size() < nev) {
         hipEvent_t e;
         GPK_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1587,12 +1613,12 @@ static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
 }
 
 int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss) {
-    const int J = gpk_ceil_div(nc, 512);
+    const int J = gpk_ceil_div(nc, 512) < 3 ? 0 : (int)pipe_blocks(nc).size() - 1;   // (orders below 1025: nothing to overlap)
     h->pipe_tev_used = 0;
     h->prof_pipelined = 0;
     // (a handle on which the CU-masked streams could not be created -- a runtime or a container that does not allow CU masks --
     // silently keeps the one-stream schedule: same results, no overlap)
-    if (!h->pipe_unavailable && g_pipeline && J >= 3 && nc <= g_pipeline_max_n && h->num_cu >= 64 && pipe_setup(h, 2 * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0) != 0) {
+    if (!h->pipe_unavailable && g_pipeline && J >= 3 && nc <= g_pipeline_max_n && h->num_cu >= 64 && pipe_setup(h, (g_pipeline_lookahead ? 4 : 2) * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0) != 0) {
         h->pipe_unavailable = true;
         (void)hipGetLastError();
     }
@@ -1616,20 +1642,27 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
 // products: left-looking 512-column block updates on the GEMM partition, panel chains on the chain partition.
 static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss,
                            int pivot_base) {
-    constexpr int OB = 512;
-    const int J = gpk_ceil_div(nc, OB);
+    const std::vector<int> bnd = pipe_blocks(nc);
+    const int J = (int)bnd.size() - 1;
     if (J < 2) return potrf_seq(h, Hb, nc, ldh, pivot_base);
-    GPK_TRY(pipe_setup(h, 2 * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
+    GPK_TRY(pipe_setup(h, (g_pipeline_lookahead ? 4 : 2) * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
     const hipStream_t main_s = h->stream, G = h->pipe_g, C = h->pipe_c;
-    // product of the blocks [jb, je): Hb[jb OB :, jb OB : je OB] = W[:, jb OB :]^T W[:, jb OB : je OB] (tiles above the diagonal skipped)
+    // product of the blocks [jb, je): Hb[b_jb :, b_jb : b_je] = W[:, b_jb :]^T W[:, b_jb : b_je] (tiles above the diagonal skipped)
     auto product = [&](int jb, int je) {
-        const int j0 = jb * OB, j1 = (je * OB < nc) ? je * OB : nc;
-        return gpk_i_gemm(h, true, false, nc - j0, j1 - j0, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
-                          lead > j0 ? lead - j0 : 0, false, true);
+        const int j0 = bnd[jb], j1 = bnd[je < J ? je : J];
+        // few tiles, long K: split K so that the launch has about g_pipeline_units workgroups (see GemmArgs::splitk)
+        const long tiles = (long)gpk_ceil_div(nc - j0, 32) * gpk_ceil_div(j1 - j0, 64);
+        h->splitk_req = g_pipeline_units > 0 ? (int)((g_pipeline_units + tiles / 2) / tiles) : 0;
+        const int r = gpk_i_gemm(h, true, false, nc - j0, j1 - j0, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
+                                 lead > j0 ? lead - j0 : 0, false, true);
+        h->splitk_req = 0;
+        return r;
     };
     hipEvent_t* ev_ready = h->pipe_ev.data();                        // [J]
     hipEvent_t* ev_chain = h->pipe_ev.data() + J;                    // [J]
     hipEvent_t ev_fork = h->pipe_ev[2 * J];
+    hipEvent_t* ev_ready2 = h->pipe_ev.data() + 2 * J + 1;           // [J] (lookahead only)
+    hipEvent_t* ev_pre = h->pipe_ev.data() + 3 * J + 1;              // [J] (lookahead only)
     int rc = 0, ntev = 0;
     auto fail = [&](hipError_t e, const char* what) { h->stream = main_s; return gpk_fail(h, e, what, __FILE__, __LINE__); };
 #define PIPE_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
@@ -1660,27 +1693,55 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
     PIPE_HIP(hipStreamWaitEvent(G, ev_fork, 0));
     PIPE_HIP(hipStreamWaitEvent(C, ev_fork, 0));
     for (int j = 0; j < J && rc == 0; ++j) {
-        const int j0 = j * OB, ob = (nc - j0 < OB) ? nc - j0 : OB, m = nc - j0;
+        const int j0 = bnd[j], ob = bnd[j + 1] - j0, m = nc - j0;
+        const int pb0 = j > 0 ? bnd[j - 1] : 0, pob = j0 - pb0;      // the previous block: first column, width
         double* Hjj = Hb + (long)j0 * ldh + j0;
         h->stream = G;
         if (j > 0) {
             const double* Lrow = Hb + (long)j0 * ldh;                // rows j0.. of the factored panels, columns 0..j0
             if (j > 1) {                                             // panels 0..j-2: their chain finished an iteration ago
-                rc = gpk_i_gemm(h, false, true, m, ob, (j - 1) * OB, -1.0, Lrow, ldh, Lrow, ldh, 1.0, Hjj, ldh, false, 0, false, true);
+                const long tiles = (long)gpk_ceil_div(m, 32) * gpk_ceil_div(ob, 64);
+                h->splitk_req = g_pipeline_units > 0 ? (int)((g_pipeline_units + tiles / 2) / tiles) : 0;
+                rc = gpk_i_gemm(h, false, true, m, ob, pb0, -1.0, Lrow, ldh, Lrow, ldh, 1.0, Hjj, ldh, false, 0, false, true);
+                h->splitk_req = 0;
+                if (rc) break;
+            }
+            // ... then block j-1, whose chain is still running: its first seven panels as soon as they are final (ev_pre), the last
+            // one (rank 64) when the chain has finished -- first into the 64 columns the chain of block j starts with (ev_ready),
+            // then into the other columns (ev_ready2, needed from the second panel on).  What lies between two block chains is
+            // two event hops and one small rank-64 launch instead of a K = 512 product over the whole block column.
+            const double* Lb = Lrow + pb0;
+            const int k1 = (g_pipeline_lookahead && pob > NB) ? pob - NB : 0;
+            if (k1 > 0) {
+                PIPE_HIP(hipStreamWaitEvent(G, ev_pre[j - 1], 0));
+                rc = gpk_i_gemm(h, false, true, m, ob, k1, -1.0, Lb, ldh, Lb, ldh, 1.0, Hjj, ldh, false, 0, false, true);
                 if (rc) break;
             }
             PIPE_HIP(hipStreamWaitEvent(G, ev_chain[j - 1], 0));
-            rc = gpk_i_gemm(h, false, true, m, ob, OB, -1.0, Lrow + (j - 1) * OB, ldh, Lrow + (j - 1) * OB, ldh, 1.0, Hjj, ldh, false, 0, false, true);
-            if (rc) break;
+            if (g_pipeline_lookahead) {
+                const int w0 = ob < NB ? ob : NB;
+                rc = gpk_i_gemm(h, false, true, m, w0, pob - k1, -1.0, Lb + k1, ldh, Lb + k1, ldh, 1.0, Hjj, ldh, false);
+                if (rc) break;
+                PIPE_HIP(hipEventRecord(ev_ready[j], G));
+                if (ob > w0) {
+                    rc = gpk_i_gemm(h, false, true, m, ob - w0, pob - k1, -1.0, Lb + k1, ldh, Lb + k1 + (long)w0 * ldh, ldh, 1.0, Hjj + w0, ldh, false);
+                    if (rc) break;
+                }
+                PIPE_HIP(hipEventRecord(ev_ready2[j], G));
+            } else {
+                rc = gpk_i_gemm(h, false, true, m, ob, pob, -1.0, Lb, ldh, Lb, ldh, 1.0, Hjj, ldh, false, 0, false, true);
+                if (rc) break;
+            }
         }
-        PIPE_HIP(hipEventRecord(ev_ready[j], G));
+        if (j == 0 || !g_pipeline_lookahead) PIPE_HIP(hipEventRecord(ev_ready[j], G));
         if (W && j + pre < J) {                                      // product of the block `pre` ahead, while the chain of block j runs
             rc = timed_product(G, j + pre, j + pre + 1);
             if (rc) break;
         }
         h->stream = C;
         PIPE_HIP(hipStreamWaitEvent(C, ev_ready[j], 0));
-        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, pivot_base + j0, g_left_looking_panels != 0);
+        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, pivot_base + j0, g_left_looking_panels != 0,
+                               (g_pipeline_lookahead && j > 0) ? ev_ready2[j] : nullptr, (g_pipeline_lookahead && j + 1 < J && ob > NB) ? ev_pre[j] : nullptr);
         if (rc) break;
         PIPE_HIP(hipEventRecord(ev_chain[j], C));
     }
@@ -1746,6 +1807,9 @@ extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; ret
 extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_widths(int key, int v) { (key == 28 ? g_pipeline_w0 : g_pipeline_ob) = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_lookahead(int v) { g_pipeline_lookahead = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_units(int v) { g_pipeline_units = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0; }
 extern "C" int gpk_debug_set_left_looking_panels(int v) { g_left_looking_panels = v; return 0; }
 extern "C" int gpk_debug_set_panel_mfma(int v) { g_panel_mfma = v; return 0; }

@@ -54,6 +54,12 @@ struct GemmArgs {
     int ntm, ntn, ntiles;
     int ntm_full;      // tri_a: number of row tiles of C (ntm counts PAIRS of them then)
     int nsuper;        // > 0: supertile schedule of the lower-triangular, leading-zero (SYRK) launch, see map_tile
+    int splitk;        // > 1: every tile's K range is cut into `splitk` chunks, one workgroup each (blockIdx = tile * splitk + chunk);
+                       // the chunks leave their accumulators in `ws`, take a ticket in cnt[tile], and the LAST arriver adds them up in
+                       // chunk order (so the result does not depend on who was last) and writes C.  For launches of few tiles with a
+                       // long K loop (the 512-column products of the pipelined phase: one wave of 100-900 tiles with K up to 8400)
+    double* ws;        // splitk: ntiles * splitk * BM * BN doubles
+    unsigned* cnt;     // splitk: one arrival counter per tile, zero before the launch, reset to zero by the last arriver
 };
 
 // KC = true : operand stored [x][k] (k contiguous);  KC = false : stored [k][x] (x contiguous)
@@ -112,12 +118,12 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
 int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
+int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
 int g_rev_k = 0;                                                     // gpk_debug_set key 16
 int g_stagger = 0;                                                   // gpk_debug_set key 15: start-time stagger of co-resident GEMM workgroups (experiment)
 int g_supertile = 0;                                                 // gpk_debug_set key 6: 1 = supertile schedule for the leading-zero SYRK (below)
 
-__device__ __forceinline__ bool map_tile(const GemmArgs& g, int& tm, int& tn) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm, int& tn) {
     if (g.nsuper > 0) {
         // OPTIONAL schedule (off by default, gpk_debug_set(6, 1)) for SYRK S^T S on lower tiles with leading zeros.  A
         // tile's K loop starts at a row that depends on its column block, so only tiles of the same column group can
@@ -193,8 +199,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     double* const As = smem;
     double* const Bs = smem + 2 * A_SZ;
 
+    const int nsplit = g.splitk;
+    const int bt = nsplit > 1 ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
+    const int chunk = nsplit > 1 ? (int)blockIdx.x - bt * nsplit : 0;
     int tm_map, tn;
-    if (!map_tile(g, tm_map, tn)) return;
+    if (!map_tile(g, bt, tm_map, tn)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
     const int li = lane & 15, lk = lane >> 4;
@@ -236,6 +245,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         kt0 = z > 0 ? (z / g.lead_div) / BK : 0;
         if (kt0 > nk) kt0 = nk;
     }
+    int kbeg = kt0, kend = nk;                                       // this workgroup's slabs
+    if (nsplit > 1) {
+        const int len = (nk - kt0 + nsplit - 1) / nsplit;
+        kbeg = min(kt0 + chunk * len, nk);
+        kend = min(kbeg + len, nk);
+    }
     auto compute = [&](int buf) {
         const double* __restrict__ as = As + buf * A_SZ;
         const double* __restrict__ bs = Bs + buf * B_SZ;
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     };
     constexpr int NA = BM * BK / 512, NB = BN * BK / 512;
-    int kdone = kt0;                                                  // slabs [kt0, kdone) are accumulated
+    int kdone = kbeg;                                                 // slabs [kbeg, kdone) are accumulated
     if (PF2) {
         // Interior tiles of aligned operands, full slabs only: two slabs in flight with STRAIGHT-LINE unguarded 16-byte
         // loads (slab index clamped instead of branched around), so that the compiler's s_waitcnt before the LDS store
@@ -265,8 +280,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         // tiles need no masking in m and n, only in-bounds addresses (clamped below; for an m-contiguous operand the last
         // 16-byte pair may read the padding element at column X, which exists because the leading dimension is even).
         const bool fast = g.vecA && g.vecB;
-        const int nkf = fast ? Kt / BK : kt0;                         // full slabs
-        if (nkf > kt0) {
+        const int nkf = fast ? min(Kt / BK, kend) : kbeg;             // full slabs
+        if (nkf > kbeg) {
             const int t = threadIdx.x;
             const double* pa[NA]; const double* pb[NB];
 #pragma unroll
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             d2 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
             auto load = [&](int kt, d2 (&ra)[NA], d2 (&rb)[NB]) {
                 int kc = min(kt, nkf - 1);                            // past the end: re-read the last slab (never used)
-                if (g.rev_k) kc = (nkf - 1) - (kc - kt0);             // walk K downwards (see GemmArgs::rev_k)
+                if (g.rev_k) kc = (nkf - 1) - (kc - kbeg);            // walk K downwards (see GemmArgs::rev_k)
 #pragma unroll
                 for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const d2*>(pa[i] + kc * sa);
 #pragma unroll
@@ -295,11 +310,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 store_tile<!TA, BM>(As + buf * A_SZ, ra);
                 store_tile<TB, BN>(Bs + buf * B_SZ, rb);
             };
-            load(kt0, ra0, rb0);
-            load(kt0 + 1, ra1, rb1);
-            store(kt0 & 1, ra0, rb0);
+            load(kbeg, ra0, rb0);
+            load(kbeg + 1, ra1, rb1);
+            store(kbeg & 1, ra0, rb0);
             __syncthreads();
-            for (int kt = kt0; kt < nkf; kt += 2) {
+            for (int kt = kbeg; kt < nkf; kt += 2) {
                 load(kt + 2, ra0, rb0);                               // registers 0 are free (slab kt sits in LDS)
                 compute(kt & 1);
                 store((kt + 1) & 1, ra1, rb1);
@@ -313,21 +328,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             kdone = nkf;
         }
     }
-    if (kdone < nk) {                                                 // edge tiles, unaligned operands, the partial slab
+    if (kdone < kend) {                                               // edge tiles, unaligned operands, the partial slab
         d2 ra[NA], rb[NB];
         load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kdone * BK, Kt, g.vecA, ra);
         load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kdone * BK, Kt, g.vecB, rb);
         store_tile<!TA, BM>(As + (kdone & 1) * A_SZ, ra);
         store_tile<TB, BN>(Bs + (kdone & 1) * B_SZ, rb);
         __syncthreads();
-        for (int kt = kdone; kt < nk; ++kt) {
+        for (int kt = kdone; kt < kend; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) {
+            if (kt + 1 < kend) {
                 load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, Kt, g.vecA, ra);
                 load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, Kt, g.vecB, rb);
             }
             compute(cur);
-            if (kt + 1 < nk) {
+            if (kt + 1 < kend) {
                 store_tile<!TA, BM>(As + (cur ^ 1) * A_SZ, ra);
                 store_tile<TB, BN>(Bs + (cur ^ 1) * B_SZ, rb);
             }
@@ -335,6 +350,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     }
 
+    if (nsplit > 1) {
+        // Hand-over across workgroups (other CUs, other XCDs: private L1s, non-coherent L2s): the accumulators leave as
+        // write-through (agent-scope, sc1) stores, every wave waits for the acknowledgements of its own, then one lane takes the
+        // ticket; the last arriver reads the chunks with sc1 loads (MI355X_MICROARCH.md, "splitk-seam").
+        const long tid = (long)tm * g.ntn + tn;
+        double* const wt = g.ws + tid * nsplit * (BM * BN);
+        double* const mine = wt + (long)chunk * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(mine + ((i * TN + j) * 256 + (int)threadIdx.x) * 4 + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // (the ticket travels through the first word of the operand buffers, which nobody reads any more: a variable of its own
+        // would cost the 64x64 TN instantiation its fourth workgroup per CU -- 4 x 40 KB are exactly the 160 KB of LDS)
+        unsigned* const s_ticket = reinterpret_cast<unsigned*>(smem);
+        if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(g.cnt + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = *s_ticket;
+        if (ticket != (unsigned)(nsplit - 1)) return;
+        if (threadIdx.x == 0) __hip_atomic_store(g.cnt + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        d4 sum[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sum[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < nsplit; ++c) {
+            const double* src = wt + (long)c * (BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sum[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 256 + (int)threadIdx.x) * 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = sum[i][j];
+    }
     const bool has_beta = (g.beta != 0.0);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -379,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
     double* const Bs = smem + NK * A_SZ;
     __builtin_amdgcn_s_setprio(3);                                   // part of a latency chain (panel loop): see potrf_panel_kernel
     int tm, tn;
-    if (!map_tile(g, tm, tn)) return;
+    if (!map_tile(g, blockIdx.x, tm, tn)) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
@@ -482,6 +541,18 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         for (int cg = 0; cg < ncg; ++cg) g.nsuper += gpk_ceil_div(T - cg * SG_W, SG_H);
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
     }
+    g.splitk = 1; g.ws = nullptr; g.cnt = nullptr;
+    int want = h->splitk_req;
+    if (want <= 1 && g_force_splitk > 1 && gpk_i_splitk_reserve(h) == 0) want = g_force_splitk;
+    if (want > 1 && !g.lower_only && !g.tri_a && h->d_splitk_ws && h->d_splitk_cnt) {
+        int s = want > 16 ? 16 : want;
+        while (s > 1 && (g.K / BK) / s < 16) --s;                    // chunks of at least 16 slabs
+        while (s > 1 && (size_t)g.ntiles * s * BM * BN * sizeof(double) > h->splitk_ws_cap) --s;
+        if (s > 1 && g.ntiles <= h->splitk_cnt_cap) {
+            g.splitk = s; g.ws = h->d_splitk_ws; g.cnt = h->d_splitk_cnt;
+            nblocks = g.ntiles * s;
+        }
+    }
     dim3 grid(nblocks), block(256);
     const size_t dyn = (size_t)g_gemm_extra_lds;
     if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true><<<grid, block, dyn, h->stream>>>(g);   // (only NN reaches here)
@@ -521,6 +592,9 @@ extern "C" int gpk_debug_set_pipeline(int v);
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
 extern "C" int gpk_debug_set_pipeline_max_n(int v);
 extern "C" int gpk_debug_set_pipeline_pre(int v);
+extern "C" int gpk_debug_set_pipeline_units(int v);
+extern "C" int gpk_debug_set_pipeline_lookahead(int v);
+extern "C" int gpk_debug_set_pipeline_widths(int key, int v);
 extern "C" int gpk_debug_set_left_looking_panels(int v);
 extern "C" int gpk_debug_set_potrf_pipeline(int key, int v);
 extern "C" int gpk_debug_set_panel_mfma(int v);
@@ -543,10 +617,14 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 14) return gpk_debug_set_pipeline_max_n(value);
     if (key == 15) { g_stagger = value; return 0; }
     if (key == 17) return gpk_debug_set_pipeline_pre(value);
+    if (key == 24) return gpk_debug_set_pipeline_units(value);
+    if (key == 26) return gpk_debug_set_pipeline_lookahead(value);
+    if (key == 28 || key == 29) return gpk_debug_set_pipeline_widths(key, value);
     if (key == 18) return gpk_debug_set_left_looking_panels(value);
     if (key == 19 || key == 20) return gpk_debug_set_potrf_pipeline(key, value);
     if (key == 21) return gpk_debug_set_panel_mfma(value);
     if (key == 16) { g_rev_k = value; return 0; }
+    if (key == 25) { g_force_splitk = value; return 0; }
     return GPK_ERR_ARG;
 }
 

@@ -139,6 +139,36 @@ def test_gemm_update_kernels(ctx, ta, tb, m, n, k, alpha):
     assert np.max(np.abs(got - want)) <= bound
 
 
+@pytest.mark.parametrize('split', [2, 3, 7])
+@pytest.mark.parametrize('ta,tb,m,n,k,beta', [(1, 0, 700, 130, 2100, 0.0), (0, 1, 500, 64, 1500, 1.0), (0, 0, 333, 200, 1111, 1.0), (1, 1, 96, 96, 4000, 0.0)])
+def test_gemm_split_k(ctx, split, ta, tb, m, n, k, beta):
+    """gpk_debug_set(25, s): every tile's K range cut into s chunks on separate workgroups, combined by the last arriver in
+    chunk order -- same bound as the unsplit kernel, and bit-identical between runs (the order of arrival does not matter)"""
+    rng = np.random.RandomState(m + n + k + split)
+    A = rng.normal(size=(k, m) if ta else (m, k))
+    B = rng.normal(size=(n, k) if tb else (k, n))
+    Cm = rng.normal(size=(m, n))
+    opA = A.T if ta else A
+    opB = B.T if tb else B
+    want = -1.0 * opA @ opB + beta * Cm
+    dA, dB = ctx.array(A), ctx.array(B)
+    ctx.lib.gpk_debug_set(25, split)
+    try:
+        runs = []
+        for _ in range(3):
+            dC = ctx.array(Cm)
+            ctx.gemm(ta, tb, m, n, k, -1.0, dA, dB, beta, dC)
+            runs.append(dC.download())
+    finally:
+        ctx.lib.gpk_debug_set(25, 0)
+    bound = 1e-13 * (np.abs(opA) @ np.abs(opB) + np.abs(Cm)).max()
+    assert np.max(np.abs(runs[0] - want)) <= bound
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    dC = ctx.array(Cm)                                               # and the unsplit launch still works on the same handle
+    ctx.gemm(ta, tb, m, n, k, -1.0, dA, dB, beta, dC)
+    assert np.max(np.abs(dC.download() - want)) <= bound
+
+
 def test_gemm_unaligned_leading_dimension(ctx):
     """odd ld / odd offsets take the scalar-load path"""
     rng = np.random.RandomState(5)
