@@ -99,6 +99,7 @@ int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl
 int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db);
 int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int db, int n, int ldl, double* B, int ldb,
                          double* X, int ldx, int nrhs, int lead, int row0);
+int gpk_i_pipe_streams(gpk_handle h);                                                   // the two CU-masked streams of the pipeline (gpk_factor.hip); called by gpk_create
 int gpk_i_splitk_reserve(gpk_handle h);                                                 // workspace + counters of the split-K launches
 int gpk_i_workspace(gpk_handle h, size_t bytes, double** out);                          // handle-owned scratch, grown on demand
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);

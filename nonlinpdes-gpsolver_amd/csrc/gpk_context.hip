@@ -40,6 +40,13 @@ extern "C" int gpk_create(int device, gpk_handle* out) {
     h->stream = h->own_stream;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+    // the CU-masked streams of the SYRK/Cholesky pipeline, created NOW (see pipe_setup in gpk_factor.hip: nothing may come between
+    // the handle's stream and them); a runtime that refuses CU masks leaves the handle on the one-stream schedule
+    if (h->num_cu >= 64 && gpk_i_pipe_streams(h) != 0) {
+        h->pipe_unavailable = true;
+        h->err.clear();
+        (void)hipGetLastError();
+    }
     *out = h;
     return 0;
 }
@@ -212,7 +219,7 @@ int gpk_i_ensure_points(gpk_handle h, size_t doubles) {
 int gpk_i_splitk_reserve(gpk_handle h) {
     if (h->d_splitk_ws) return 0;
     constexpr size_t WS = (size_t)64 << 20;
-    constexpr int NCNT = 16384;
+    constexpr int NCNT = 65536;
     GPK_HIP(h, hipMalloc(&h->d_splitk_cnt, NCNT * sizeof(unsigned)));
     GPK_HIP(h, hipMemset(h->d_splitk_cnt, 0, NCNT * sizeof(unsigned)));
     h->splitk_cnt_cap = NCNT;

@@ -1343,6 +1343,7 @@ __global__ void dinv_identity_kernel(double* __restrict__ D, int n, int db) {
     if (i < (long)n * db) D[i] = ((i / db) % db == i % db) ? 1.0 : 0.0;
 }
 
+int g_solve_splitk = 0;                                              // gpk_debug_set key 30: largest split-K factor tried for the updates of the inverted-block solve (0 = off)
 inline bool dinv_block_ok(int db) { return db == 256 || db == 512 || db == 1024; }
 
 int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db) {
@@ -1379,8 +1380,23 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
     c1 = c1 > 0 ? (c1 / NB) * NB : 0;
     if (c1 < nrhs) {
         const int lz = lead - sd * row0 - c1;
-        GPK_TRY(gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, X + c1, ldx, 1.0, B + (long)n1 * ldb + c1, ldb,
-                           false, lz > 0 ? lz : 0));
+        if (g_solve_splitk && gpk_i_splitk_reserve(h) == 0) {
+            // launches that fill the chip badly (a fraction of a wave, or 1.2 waves): more, shorter workgroups (split-K)
+            const long t64 = (long)gpk_ceil_div(n2, 64) * gpk_ceil_div(nrhs - c1, 64);
+            const bool small = t64 < 2 * h->num_cu;                  // (gpk_i_gemm then uses 32-row tiles, 5 per CU)
+            const long tiles = small ? (long)gpk_ceil_div(n2, 32) * gpk_ceil_div(nrhs - c1, 64) : t64;
+            const long slots = (long)h->num_cu * (small ? 5 : 4);
+            int best = 1; double bc = 1e30;
+            for (int s2 = 1; s2 <= g_solve_splitk; ++s2) {
+                const double c = (double)((tiles * s2 + slots - 1) / slots) / s2 + 0.04 * (s2 - 1);
+                if (c < bc - 1e-9) { bc = c; best = s2; }
+            }
+            h->splitk_req = best;
+        }
+        const int rc = gpk_i_gemm(h, false, false, n2, nrhs - c1, n1, -1.0, L21, ldl, X + c1, ldx, 1.0, B + (long)n1 * ldb + c1, ldb,
+                                  false, lz > 0 ? lz : 0);
+        h->splitk_req = 0;
+        GPK_TRY(rc);
     }
     return gpk_i_trsm_left_dinv(h, L21 + n1, Dinv, db, n2, ldl, B + (long)n1 * ldb, ldb, X + (long)n1 * ldx, ldx, nrhs, lead, row0 + n1);
 }
@@ -1482,9 +1498,8 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             // On the whole chip the right-looking form is faster (the long-K product on ~110 workgroups is latency-bound:
             // 4.42 vs 4.25 ms for the phase), so it remains the default everywhere else.
             // (Tried in round 2: the contributions of the panels up to p-2 on a SECOND stream of the same partition, next to panel
-            // p-1's kernel, so that only a rank-64 update stays between two panel kernels.  Not adoptable: the mere existence of one
-            // more stream on the handle -- CU-masked or plain, used or not -- made EVERY kernel of the step slower, the solve
-            // phase included (7.2 -> 9.1 ms per step; single launches +40 %..+350 %).)
+            // p-1's kernel, so that only a rank-64 update stays between two panel kernels.  Not possible on this runtime: a fourth
+            // stream in use shares a hardware queue with one of the others -- CU mask included -- see pipe_setup.)
             GPK_TRY(gpk_i_gemm(h, false, true, nrows - j0, nb, j0, -1.0, A + (long)j0 * lda, lda, A + (long)j0 * lda, lda, 1.0, Ajj, lda, false));
         }
         if (g_fused_panel) {
@@ -1575,6 +1590,7 @@ int g_pipeline_max_n = 5000;                                         // gpk_debu
 // Block columns of the pipelined factorisation: a first block of g_pipeline_w0 columns (the chain can only start once its product is
 // there), then blocks of g_pipeline_ob columns; widths are multiples of the panel width, at most 512.
 int g_pipeline_w0 = 512, g_pipeline_ob = 512;                        // gpk_debug_set keys 28 / 29
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev);
 static std::vector<int> pipe_blocks(int nc) {
     auto norm = [](int w) { w = (w / NB) * NB; return w < NB ? NB : (w > 512 ? 512 : w); };
     std::vector<int> b{0};
@@ -1582,6 +1598,15 @@ static std::vector<int> pipe_blocks(int nc) {
     while (b.back() < nc) { b.push_back(b.back() + w < nc ? b.back() + w : nc); w = norm(g_pipeline_ob); }
     return b;
 }
+
+// The two masked streams are created by gpk_create, right after the handle's own stream, and again here only when the partition
+// size is changed (development switch).  The order matters on this runtime (measured, round 2, tools/alias_probe.py): with ONE other
+// stream created between the handle's stream and the masked ones -- used or not -- every phase of the step ran slower (solve +14 %,
+// pipelined phase 3.6 -> 4.6 ms; two such streams: 10 ms), and so did a FOURTH stream in use (a second chain stream was tried for
+// the panels' early updates).  HIP multiplexes streams onto a few hardware queues, and streams that land on the same queue
+// serialise; streams created before the context (torch's pool) or after the masked pair did no harm.  GPU_MAX_HW_QUEUES = 8 changed
+// nothing.
+int gpk_i_pipe_streams(gpk_handle h) { return pipe_setup(h, 0, 0); }
 
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
     // multiples of 32: bits 8k .. 8k+7 of the mask are one CU of shader engine k mod 4 on each of the 8 XCDs, so 32 bits take one CU from
@@ -1808,6 +1833,7 @@ extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_widths(int key, int v) { (key == 28 ? g_pipeline_w0 : g_pipeline_ob) = v; return 0; }
+extern "C" int gpk_debug_set_solve_splitk(int v) { g_solve_splitk = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_lookahead(int v) { g_pipeline_lookahead = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_units(int v) { g_pipeline_units = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0; }
