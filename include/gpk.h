@@ -174,7 +174,8 @@ int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* host_prob, const doub
 /* development aids (process-wide): key 0 = force the GEMM tile configuration (0 auto, 1 = 128x128, 2 = 64x64);
  * key 2 = run multi-RHS triangular solves as 4 column groups on concurrent streams (0 off, default); key 10 = 0: substitution
  * strips even when Dinv is given; key 12 = 0: SYRK then right-looking Cholesky on one stream instead of the two-partition
- * pipeline; key 13 = CUs of the chain partition (default 64); the full list is in tools/README.md */
+ * pipeline; key 13 = CUs of the chain partition (default 32); key 24 = workgroups per split-K product launch of the pipeline
+ * (default 1000, 0 = no split); the full list is in tools/README.md */
 int gpk_debug_set(int key, int value);
 /* development aid: enable/disable and read the shader-clock phase stamps of the 64-wide diagonal-block kernels */
 int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable);

@@ -357,13 +357,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const long tid = (long)tm * g.ntn + tn;
         double* const wt = g.ws + tid * nsplit * (BM * BN);
         double* const mine = wt + (long)chunk * (BM * BN);
+        // (16-byte write-through stores: two per accumulator tile and lane; as 8-byte agent-scope atomics they cost 2.7x per byte)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    __hip_atomic_store(mine + ((i * TN + j) * 256 + (int)threadIdx.x) * 4 + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < TN; ++j) {
+                double* dst = mine + ((i * TN + j) * 256 + (int)threadIdx.x) * 4;
+                const d2 lo = (d2){acc[i][j][0], acc[i][j][1]}, hi = (d2){acc[i][j][2], acc[i][j][3]};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(dst), "v"(lo), "v"(hi) : "memory");
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // (the ticket travels through the first word of the operand buffers, which nobody reads any more: a variable of its own
@@ -381,13 +383,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             for (int j = 0; j < TN; ++j) sum[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
         for (int c = 0; c < nsplit; ++c) {
             const double* src = wt + (long)c * (BM * BN);
+            d2 lo[TM][TN], hi[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    const double* p = src + ((i * TN + j) * 256 + (int)threadIdx.x) * 4;
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1" : "=&v"(lo[i][j]), "=&v"(hi[i][j]) : "v"(p) : "memory");
+                }
+            // (the compiler does not track loads issued from inline asm: the wait is tied to every destination register pair, so
+            // that no use can be scheduled ahead of it)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        sum[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * 256 + (int)threadIdx.x) * 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo[i][j]), "+v"(hi[i][j]) :: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    sum[i][j][0] += lo[i][j].x; sum[i][j][1] += lo[i][j].y;
+                    sum[i][j][2] += hi[i][j].x; sum[i][j][3] += hi[i][j].y;
+                }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -663,6 +679,9 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // (also for long K: restricting this to K <= 1024 was measured slower on the 512-column products of the pipelined SYRK and on
     // the mid-size updates of the triangular solve -- 504 tiles of 64x64 leave the CUs at 2-3 workgroups)
     if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
+    // (A "round model" -- co-resident workgroups start and finish together, a partly filled last round costs at least half a round, so
+    // e.g. 1260 tiles of 64 rows should lose against 2457 tiles of 32 rows -- was tried as the selector and is wrong for this kernel:
+    // 383 -> 420 us for that launch, 1384 -> 1477 us for the 3276-tile one; only launches below 0.6 rounds gained, 121 -> 105 us.)
     return launch_cfg<64, 64, 32, 32>(h, ta, tb, g);
 }
 
