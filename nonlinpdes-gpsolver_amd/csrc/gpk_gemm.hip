@@ -63,15 +63,15 @@ struct GemmArgs {
 };
 
 // KC = true : operand stored [x][k] (k contiguous);  KC = false : stored [k][x] (x contiguous)
-template <bool KC, int BX>
+template <bool KC, int BX, int NT = 256>
 __device__ __forceinline__ void load_tile(const double* __restrict__ P, long ld, int x0, int X, int k0, int K, bool vec,
-                                          d2 (&r)[BX * BK / 512]) {
+                                          d2 (&r)[BX * BK / (2 * NT)]) {
     const int t = threadIdx.x;
     // interior tiles (workgroup-uniform test -> scalar branch): unguarded 16-byte loads
     if (vec && x0 + BX <= X && k0 + BK <= K) {
 #pragma unroll
-        for (int i = 0; i < BX * BK / 512; ++i) {
-            const int lin = t + 256 * i;
+        for (int i = 0; i < BX * BK / (2 * NT); ++i) {
+            const int lin = t + NT * i;
             const double* ptr = KC ? P + (long)(x0 + lin / (BK / 2)) * ld + k0 + (lin % (BK / 2)) * 2
                                    : P + (long)(k0 + lin / (BX / 2)) * ld + x0 + (lin % (BX / 2)) * 2;
             r[i] = *reinterpret_cast<const d2*>(ptr);
@@ -80,8 +80,8 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ P, long ld,
     }
     // edge tiles / unaligned operands: clamped addresses + selects (no divergent branches)
 #pragma unroll
-    for (int i = 0; i < BX * BK / 512; ++i) {
-        const int lin = t + 256 * i;
+    for (int i = 0; i < BX * BK / (2 * NT); ++i) {
+        const int lin = t + NT * i;
         int x, k;
         if (KC) { x = x0 + lin / (BK / 2); k = k0 + (lin % (BK / 2)) * 2; }
         else    { k = k0 + lin / (BX / 2); x = x0 + (lin % (BX / 2)) * 2; }
@@ -96,12 +96,12 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ P, long ld,
     }
 }
 
-template <bool KC, int BX>
-__device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&r)[BX * BK / 512]) {
+template <bool KC, int BX, int NT = 256>
+__device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&r)[BX * BK / (2 * NT)]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < BX * BK / 512; ++i) {
-        const int lin = t + 256 * i;
+    for (int i = 0; i < BX * BK / (2 * NT); ++i) {
+        const int lin = t + NT * i;
         int off;
         if (KC) off = (lin / (BK / 2)) * (BK + 2) + (lin % (BK / 2)) * 2;
         else    off = (lin / (BX / 2)) * (BX + 16) + (lin % (BX / 2)) * 2;
@@ -118,6 +118,7 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
 int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
+int g_tall_min = 1500;                                               // gpk_debug_set key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
 int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
 int g_rev_k = 0;                                                     // gpk_debug_set key 16
 int g_stagger = 0;                                                   // gpk_debug_set key 15: start-time stagger of co-resident GEMM workgroups (experiment)
@@ -188,11 +189,12 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
 }
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool TRI = false>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f64_kernel(GemmArgs g) {
     constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr bool PF2 = (BM * BN <= 64 * 64);                      // prefetch depth 2 for the small-tile configuration
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;                   // threads: 4 waves, or 8 for the 128 x 64 tile
+    constexpr bool PF2 = (BM * BN <= 64 * 64) || NT == 512;                     // prefetch depth 2 for the small-tile configuration
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
     constexpr int A_SZ = TA ? BK * (BM + 16) : BM * (BK + 2);
     constexpr int B_SZ = TB ? BN * (BK + 2) : BK * (BN + 16);
     __shared__ __attribute__((aligned(16))) double smem[2 * (A_SZ + B_SZ)];
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    constexpr int NA = BM * BK / 512, NB = BN * BK / 512;
+    constexpr int NA = BM * BK / (2 * NT), NB = BN * BK / (2 * NT);
     int kdone = kbeg;                                                 // slabs [kbeg, kdone) are accumulated
     if (PF2) {
         // Interior tiles of aligned operands, full slabs only: two slabs in flight with STRAIGHT-LINE unguarded 16-byte
@@ -286,13 +288,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
             const double* pa[NA]; const double* pb[NB];
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int lin = t + 256 * i;
+                const int lin = t + NT * i;
                 pa[i] = !TA ? g.A + (long)min(m0 + lin / (BK / 2), g.M - 1) * g.lda + (lin % (BK / 2)) * 2
                             : g.A + (long)(lin / (BM / 2)) * g.lda + min(m0 + (lin % (BM / 2)) * 2, (g.M - 1) & ~1);
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int lin = t + 256 * i;
+                const int lin = t + NT * i;
                 pb[i] = TB ? g.B + (long)min(n0 + lin / (BK / 2), g.N - 1) * g.ldb + (lin % (BK / 2)) * 2
                            : g.B + (long)(lin / (BN / 2)) * g.ldb + min(n0 + (lin % (BN / 2)) * 2, (g.N - 1) & ~1);
             }
@@ -307,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
                 for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const d2*>(pb[i] + kc * sb);
             };
             auto store = [&](int buf, const d2 (&ra)[NA], const d2 (&rb)[NB]) {
-                store_tile<!TA, BM>(As + buf * A_SZ, ra);
-                store_tile<TB, BN>(Bs + buf * B_SZ, rb);
+                store_tile<!TA, BM, NT>(As + buf * A_SZ, ra);
+                store_tile<TB, BN, NT>(Bs + buf * B_SZ, rb);
             };
             load(kbeg, ra0, rb0);
             load(kbeg + 1, ra1, rb1);
@@ -330,21 +332,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
     if (kdone < kend) {                                               // edge tiles, unaligned operands, the partial slab
         d2 ra[NA], rb[NB];
-        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kdone * BK, Kt, g.vecA, ra);
-        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kdone * BK, Kt, g.vecB, rb);
-        store_tile<!TA, BM>(As + (kdone & 1) * A_SZ, ra);
-        store_tile<TB, BN>(Bs + (kdone & 1) * B_SZ, rb);
+        load_tile<!TA, BM, NT>(g.A, g.lda, m0, g.M, kdone * BK, Kt, g.vecA, ra);
+        load_tile<TB, BN, NT>(g.B, g.ldb, n0, g.N, kdone * BK, Kt, g.vecB, rb);
+        store_tile<!TA, BM, NT>(As + (kdone & 1) * A_SZ, ra);
+        store_tile<TB, BN, NT>(Bs + (kdone & 1) * B_SZ, rb);
         __syncthreads();
         for (int kt = kdone; kt < kend; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < kend) {
-                load_tile<!TA, BM>(g.A, g.lda, m0, g.M, (kt + 1) * BK, Kt, g.vecA, ra);
-                load_tile<TB, BN>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, Kt, g.vecB, rb);
+                load_tile<!TA, BM, NT>(g.A, g.lda, m0, g.M, (kt + 1) * BK, Kt, g.vecA, ra);
+                load_tile<TB, BN, NT>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, Kt, g.vecB, rb);
             }
             compute(cur);
             if (kt + 1 < kend) {
-                store_tile<!TA, BM>(As + (cur ^ 1) * A_SZ, ra);
-                store_tile<TB, BN>(Bs + (cur ^ 1) * B_SZ, rb);
+                store_tile<!TA, BM, NT>(As + (cur ^ 1) * A_SZ, ra);
+                store_tile<TB, BN, NT>(Bs + (cur ^ 1) * B_SZ, rb);
             }
             __syncthreads();
         }
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                double* dst = mine + ((i * TN + j) * 256 + (int)threadIdx.x) * 4;
+                double* dst = mine + ((i * TN + j) * NT + (int)threadIdx.x) * 4;
                 const d2 lo = (d2){acc[i][j][0], acc[i][j][1]}, hi = (d2){acc[i][j][2], acc[i][j][3]};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(dst), "v"(lo), "v"(hi) : "memory");
             }
@@ -381,29 +383,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) sum[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        // (compiler-visible 8-byte agent-scope loads: loads issued from inline asm are not tracked, and with the large tile
+        // configurations the compiler spilled their destination registers before the data had arrived)
         for (int c = 0; c < nsplit; ++c) {
             const double* src = wt + (long)c * (BM * BN);
-            d2 lo[TM][TN], hi[TM][TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const double* p = src + ((i * TN + j) * 256 + (int)threadIdx.x) * 4;
-                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1" : "=&v"(lo[i][j]), "=&v"(hi[i][j]) : "v"(p) : "memory");
-                }
-            // (the compiler does not track loads issued from inline asm: the wait is tied to every destination register pair, so
-            // that no use can be scheduled ahead of it)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo[i][j]), "+v"(hi[i][j]) :: "memory");
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    sum[i][j][0] += lo[i][j].x; sum[i][j][1] += lo[i][j].y;
-                    sum[i][j][2] += hi[i][j].x; sum[i][j][3] += hi[i][j].y;
-                }
+                    for (int r = 0; r < 4; ++r)
+                        sum[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * NT + (int)threadIdx.x) * 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -569,7 +559,7 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
             nblocks = g.ntiles * s;
         }
     }
-    dim3 grid(nblocks), block(256);
+    dim3 grid(nblocks), block((BM / WM) * (BN / WN) * 64);
     const size_t dyn = (size_t)g_gemm_extra_lds;
     if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true><<<grid, block, dyn, h->stream>>>(g);   // (only NN reaches here)
     else if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, dyn, h->stream>>>(g);
@@ -643,6 +633,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 21) return gpk_debug_set_panel_mfma(value);
     if (key == 16) { g_rev_k = value; return 0; }
     if (key == 25) { g_force_splitk = value; return 0; }
+    if (key == 33) { g_tall_min = value; return 0; }
     return GPK_ERR_ARG;
 }
 
@@ -672,6 +663,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
     const bool big = (g_force_cfg == 1) && !g.tri_a;
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
+    if ((g_force_cfg == 3 || (g_force_cfg == 0 && g_tall_min > 0 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_tall_min)) && !g.tri_a && !lower_only)
+        return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);            // 8 waves, 2 workgroups per CU
     // short-and-wide updates of the triangular-solve recursion (M = 256 or 512 against ~4000 columns): 64x64 tiles give
     // only 1-2 workgroups per CU, i.e. one wave per SIMD and nothing to hide latency behind; 32x64 tiles double that
     long t64 = (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64);

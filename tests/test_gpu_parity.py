@@ -120,6 +120,30 @@ def test_gemm(ctx, ta, tb, m, n, k):
     assert np.max(np.abs(got - want)) <= bound
 
 
+@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('m,n,k', [(130, 70, 33), (257, 513, 100), (1, 7, 5), (700, 900, 129), (128, 64, 16)])
+def test_gemm_forced_tile_configurations(ctx, cfg, ta, tb, m, n, k):
+    """gpk_debug_set(0, c): 128x128 tiles, 64x64 tiles, and the 128x64 tile with 8 waves (the one large launches take by default) on
+    ragged shapes -- every instantiation of the kernel template is exercised whatever the size heuristics pick"""
+    rng = np.random.RandomState(m + n + k + cfg)
+    A = rng.normal(size=(k, m) if ta else (m, k))
+    B = rng.normal(size=(n, k) if tb else (k, n))
+    Cm = rng.normal(size=(m, n))
+    opA = A.T if ta else A
+    opB = B.T if tb else B
+    want = 1.7 * opA @ opB - 0.3 * Cm
+    dA, dB, dC = ctx.array(A), ctx.array(B), ctx.array(Cm)
+    ctx.lib.gpk_debug_set(0, cfg)
+    try:
+        ctx.gemm(ta, tb, m, n, k, 1.7, dA, dB, -0.3, dC)
+        got = dC.download()
+    finally:
+        ctx.lib.gpk_debug_set(0, 0)
+    bound = 1e-13 * (np.abs(opA) @ np.abs(opB) + np.abs(Cm)).max()
+    assert np.max(np.abs(got - want)) <= bound
+
+
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k,alpha', [(1000, 64, 448, -1.0), (300, 33, 200, 1.0), (257, 64, 65, -1.0), (4000, 50, 512, -1.0), (640, 64, 64, -1.0)])
 def test_gemm_update_kernels(ctx, ta, tb, m, n, k, alpha):
