@@ -323,7 +323,7 @@ def run_single(args, workload, comm=None):
     # dominant kernel of the step: gemm_f64_kernel<NN> = the whole solve phase S = L^{-1}[A | F] (GEMMs only since round 2)
     trsm_ms = prof['trsm_ms'] / steps
     uses_dinv = prob.Dinv is not None and os.environ.get('GPK_DEBUG_SET', '').find('10=0') < 0
-    trsm_flops, trsm_launches = trsm_dinv_executed_flops(N, nz, gpk.device.DINV_BLOCK) if uses_dinv else (None, None)
+    trsm_flops, trsm_launches = trsm_dinv_executed_flops(N, nz, gpk.device.dinv_block_for(N)) if uses_dinv else (None, None)
     trsm_achieved = trsm_flops / (trsm_ms * 1e-3) / 1e12 if trsm_flops else None
     out = {
         'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
@@ -466,7 +466,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
     # one-time companion of the factor: inverses of its 1024-row diagonal blocks (the column solves then are GEMMs only);
     # S2 receives the solved block out of place and is zero where the solve never writes
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    Dinv = ops.trtri_diag(Theta, N, block=gpk.device.DINV_BLOCK)
+    Dinv = ops.trtri_diag(Theta, N, block=gpk.device.DINV_BLOCK or 1024)
     torch.cuda.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
     S2 = torch.zeros((N, lds), dtype=torch.float64, device=dev)
     losses = []

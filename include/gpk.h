@@ -116,7 +116,7 @@ int gpk_gemm_lz(gpk_handle h, int ta, int m, int n, int k, double alpha, const d
                 const double* B, int ldb, double beta, double* C, int ldc, int lead);
 /* Companion of a Cholesky factor that is reused for many multi-right-hand-side forward solves (the factor of Theta in
  * GN_method: jnp.linalg.solve(self.L, .) inside every Hessian_GN, src/PDEs.py:97,306,450; src/InverseProblems.py:145-146):
- * Dinv (n x block doubles, leading dimension block; block = 256, 512 or 1024) receives the inverses of the block x block
+ * Dinv (n x block doubles, leading dimension block; block = 256, 512, 1024 or 2048) receives the inverses of the block x block
  * diagonal blocks of L, block k in rows [k block, k block + n_k), computed by substitution.  gpk_trsm_dinv then solves
  * L X = B with GEMMs only: X (n x nrhs, ld ldx, must not alias B) receives L^{-1} B, B is overwritten with intermediate
  * values.  lead > 0: column c < lead of B is zero above row lead-1-c (as gpk_trsm_lz); the zero part of X left of that

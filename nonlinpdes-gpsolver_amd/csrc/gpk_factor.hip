@@ -1344,11 +1344,11 @@ __global__ void dinv_identity_kernel(double* __restrict__ D, int n, int db) {
 }
 
 int g_solve_splitk = 0;                                              // gpk_debug_set key 30: largest split-K factor tried for the updates of the inverted-block solve (0 = off)
-inline bool dinv_block_ok(int db) { return db == 256 || db == 512 || db == 1024; }
+inline bool dinv_block_ok(int db) { return db == 256 || db == 512 || db == 1024 || db == 2048; }
 
 int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db) {
     if (n <= 0) return 0;
-    if (!dinv_block_ok(db)) return gpk_bad_arg(h, "trtri_diag: block size must be 256, 512 or 1024");
+    if (!dinv_block_ok(db)) return gpk_bad_arg(h, "trtri_diag: block size must be 256, 512, 1024 or 2048");
     dinv_identity_kernel<<<(unsigned)(((long)n * db + 255) / 256), 256, 0, h->stream>>>(Dinv, n, db);
     GPK_LAUNCH_CHECK(h);
     for (int k0 = 0; k0 < n; k0 += db) {
@@ -1890,7 +1890,7 @@ extern "C" int gpk_trtri_diag(gpk_handle h, const double* L, int n, int ldl, dou
 extern "C" int gpk_trsm_dinv(gpk_handle h, const double* L, const double* Dinv, int block, int n, int ldl, double* B, int nrhs, int ldb,
                              double* X, int ldx, int lead) {
     if (!h || !L || !Dinv || !B || !X || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs || ldx < nrhs) return GPK_ERR_ARG;
-    if (!dinv_block_ok(block)) return gpk_bad_arg(h, "trsm_dinv: block size must be 256, 512 or 1024");
+    if (!dinv_block_ok(block)) return gpk_bad_arg(h, "trsm_dinv: block size must be 256, 512, 1024 or 2048");
     if (B == X) return gpk_bad_arg(h, "trsm_dinv: X must not alias B");
     return gpk_i_trsm_left_dinv(h, L, Dinv, block, n, ldl, B, ldb, X, ldx, nrhs, lead > 0 ? lead : 0, 0);
 }

@@ -196,7 +196,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
     bool dinv = g_use_dinv != 0;
     const int db = p->dinv_block > 0 ? p->dinv_block : 256;
-    if (db != 256 && db != 512 && db != 1024) return gpk_bad_arg(h, "gn: dinv_block must be 256, 512 or 1024");
+    if (db != 256 && db != 512 && db != 1024 && db != 2048) return gpk_bad_arg(h, "gn: dinv_block must be 256, 512, 1024 or 2048");
     for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) dinv = false;
     double* W = S;
     if (dinv) {

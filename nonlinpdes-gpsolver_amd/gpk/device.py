@@ -10,7 +10,16 @@ from ._lib import GNProblemStruct, GpkError, load_library
 LAYOUT = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_u': 2, 'Darcy_a': 3}
 KERNEL = {'Gaussian': 0, 'anisotropic_Gaussian': 1}
 NUGGET = {'none': 0, 'identity': 1, 'adaptive': 2}
-DINV_BLOCK = int(__import__('os').environ.get('GPK_DINV_BLOCK', '1024'))   # rows per inverted diagonal block of a factor (256, 512, 1024)
+DINV_BLOCK = int(__import__('os').environ.get('GPK_DINV_BLOCK', '0'))   # rows per inverted diagonal block of a factor (256 .. 2048); 0 = by size
+
+
+def dinv_block_for(n):
+    """Rows per inverted diagonal block for a factor of order n: GPK_DINV_BLOCK when set, else 1024, or 2048 from order 6000 on (the
+    solve phase then has 5 instead of 9 triangular products at BASELINE config 2: 3.3 -> 3.15 ms per step; iterates agree with the
+    substitution path to ~1e-12 there, tests/test_gpu_parity.py::test_trsm_dinv and DESIGN.md section 4 'Numerics')."""
+    if DINV_BLOCK:
+        return DINV_BLOCK
+    return 2048 if n >= 6000 else 1024
 SYSTEM = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_flow2d': 3, 'Nonlinear_elliptic_relaxed': 4}
 
 
@@ -90,7 +99,7 @@ class GNProblem:
 
     def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True):
         """dinv: also compute the inverses of the diagonal blocks of the factor(s) once (gpk_trtri_diag; True = blocks of
-        DINV_BLOCK rows, or 256 / 512 / 1024), so that the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
+        dinv_block_for(order) rows, or 256 / 512 / 1024 / 2048), so that the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
         self.ctx = ctx
         self.keep = []
         def dev(v):
@@ -110,7 +119,7 @@ class GNProblem:
         s.data_u = self.data_u.ptr if self.data_u is not None else None
         s.L, s.ldl = L.ptr, L.ld
         s.L2, s.ldl2 = (L2.ptr, L2.ld) if L2 is not None else (None, 0)
-        block = DINV_BLOCK if dinv is True else int(dinv)
+        block = dinv_block_for(L.rows) if dinv is True else int(dinv)
         self.Dinv = ctx.trtri_diag(L, block=block) if dinv else None
         self.Dinv2 = ctx.trtri_diag(L2, block=block) if (dinv and L2 is not None) else None
         s.Dinv = self.Dinv.ptr if self.Dinv is not None else None
@@ -263,7 +272,7 @@ class Context:
     def trtri_diag(self, L, n=None, block=None):
         """inverses of the block x block diagonal blocks of the factor L -> (n, block) device array (gpk_trtri_diag)"""
         n = L.rows if n is None else n
-        block = DINV_BLOCK if block is None else int(block)
+        block = dinv_block_for(n) if block is None else int(block)
         D = DeviceArray(self, n, block, ld=block)
         self._chk(self.lib.gpk_trtri_diag(self.h, L.ptr, n, L.ld, D.ptr, block))
         return D

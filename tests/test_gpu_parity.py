@@ -261,10 +261,10 @@ def test_trsm(ctx, trans, n, nrhs):
 
 
 @pytest.mark.parametrize('n,nrhs,lead', [(64, 64, 0), (256, 100, 0), (300, 77, 0), (1000, 257, 0), (1537, 1001, 0), (2360, 1101, 1100),
-                                         (1924, 901, 900), (700, 650, 649), (513, 300, 200)])
-@pytest.mark.parametrize('block', [256, 512, 1024])
+                                         (1924, 901, 900), (700, 650, 649), (513, 300, 200), (4300, 513, 500)])
+@pytest.mark.parametrize('block', [256, 512, 1024, 2048])
 def test_trsm_dinv(ctx, n, nrhs, lead, block):
-    """All-GEMM forward solve through the explicit inverses of the diagonal blocks (256, 512 or 1024 rows; gpk_trtri_diag + gpk_trsm_dinv)
+    """All-GEMM forward solve through the explicit inverses of the diagonal blocks (256 .. 2048 rows; gpk_trtri_diag + gpk_trsm_dinv)
     against numpy and against the substitution path; lead > 0: right-hand sides with the leading-zero shape of [A | F]."""
     rng = np.random.RandomState(n + nrhs)
     L = np.tril(rng.normal(size=(n, n))) + np.diag(rng.uniform(3, 4, n) * np.sqrt(n))
