@@ -363,9 +363,9 @@ def run_single(args, workload, comm=None):
                      'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
                      'traffic': traffic, 'traffic_source': traffic_source, 'flops_per_launch': syrk_flops, 'dense_flops_per_launch': syrk_dense,
                      'dense_equivalent_tflops': syrk_dense / (syrk_ms * 1e-3) / 1e12, 'avg_launch_ms': syrk_ms,
-                     'launches_per_step': max((nz + 1 + 511) // 512 - 1, 1) if pipelined else 1,
-                     'launch_shape': ('blocks 0-1 (1024 columns) in one launch on the whole chip, then one launch per 512-column block on '
-                                      'the GEMM partition' if pipelined else 'one launch, lower tiles'),
+                     'launches_per_step': (nz + 1 + 511) // 512 if pipelined else 1,
+                     'launch_shape': ('block 0 (512 columns) as one launch on the whole chip, then one split-K launch per 512-column block on '
+                                      'the GEMM partition (K cut so that a launch has ~1000 workgroups)' if pipelined else 'one launch, lower tiles'),
                      'cus_available_to_kernel': gemm_cus,
                      'frac_of_partition_peak': achieved / (FP64_MFMA_PEAK_TFLOPS * gemm_cus / 256.0),
                      'launched_flops_per_step': syrk_launched,
