@@ -387,14 +387,15 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
 }
 
 // ---- Cholesky panel step, fused: factor the <=64-wide diagonal block AND solve the rows below against it ----------
-// Workgroup 0 factors A_jj and writes it back; every other workgroup owns 64 rows below, factors its own copy of A_jj
+// ONE workgroup (the last) factors A_jj and writes it back; every other workgroup owns 64 rows below, factors its own copy of A_jj
 // in LDS (redundant, but off nobody's critical path: the alternative is a second launch that first waits for the
 // factor to travel through memory) with its 64 rows riding along as extra rows of the right-looking loop (potf2_tile<true>):
 // the scaled and updated extra rows ARE X = A_rj L_jj^{-T}.  One launch instead of two per panel, 41 KB of LDS.
 // A_jj is overwritten in place, so workgroup 0 may only store once every other workgroup has READ the unfactored block
 // -- including those the hardware dispatches late when the grid exceeds what is resident (n > ~16000).  Each workgroup
-// takes a ticket on a global counter after its loads have landed; workgroup 0 waits for the running total `target`
-// (the counter is never reset: the host passes the cumulative number of tickets).  Nobody ever waits for workgroup 0.
+// takes a ticket on a global counter after its loads have landed; the storing workgroup waits for the running total `target`
+// (the counter is never reset: the host passes the cumulative number of tickets).  Nobody ever waits for the storing workgroup,
+// and since round 2 that is the LAST workgroup of the grid: it waits only for workgroups that were dispatched before it.
 __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, long lda, int nb, int below,
                                                           int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
     // 37.4 KB of LDS in total: must stay below the 40 KB of a GEMM workgroup (four of those fill a CU's 160 KB), so that a
@@ -402,15 +403,16 @@ __global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A
     __shared__ double As[NB * XS];
     __shared__ __attribute__((aligned(16))) double Ps[8 * NB];       // potf2_tile's column exchange: 2 parities x 4 vectors
     __builtin_amdgcn_s_setprio(3);                                   // latency chain: win issue arbitration against co-resident GEMM waves
-    const int c0 = ((int)blockIdx.x - 1) * NB;                       // blocks > 0: my 64 rows below the diagonal block
+    const bool last = blockIdx.x + 1 == gridDim.x;                   // the LAST workgroup factors and stores A_jj (it only ever waits for workgroups dispatched before it)
+    const int c0 = (int)blockIdx.x * NB;                             // the others: my 64 rows below the diagonal block
 #define PANEL_STAMP(i) do { if (dbg && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
     PANEL_STAMP(0);
     double xr[16];
-    if (blockIdx.x > 0) potf2_fetch_extra(A + (long)(nb + c0) * lda, lda, min(NB, below - c0), nb, xr);   // same round trip as A_jj
+    if (!last) potf2_fetch_extra(A + (long)(nb + c0) * lda, lda, min(NB, below - c0), nb, xr);   // same round trip as A_jj
     potf2_stage(A, lda, nb, As);
     __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
     PANEL_STAMP(1);
-    if (blockIdx.x == 0) {
+    if (last) {
         const int bad = potf2_tile<false>(As, Ps, nb);
         __shared__ int expired;
         if (threadIdx.x == 0) {
@@ -512,8 +514,10 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = l & 15, lk = l >> 4;
-    const bool tall = blockIdx.x > 0;
-    const int c0 = ((int)blockIdx.x - 1) * NB;
+    // (the LAST workgroup stores A_jj: it waits for tickets of workgroups with smaller indices only, which are dispatched first --
+    // with workgroup 0 in that role a grid that is not fully resident can starve, see potrf_panel_la_kernel)
+    const bool tall = blockIdx.x + 1 < gridDim.x;
+    const int c0 = (int)blockIdx.x * NB;
     const int xrows = tall ? min(NB, below - c0) : 0;
     double* __restrict__ Xg = A + (long)(nb + (tall ? c0 : 0)) * lda;   // my 64 rows below the diagonal block
     const bool rows_diag = (w < 2);                                  // waves 0, 1: rows of A_jj; waves 2, 3: extra rows
@@ -695,6 +699,314 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
         const int bad = sh_bad;
         if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, pivot_base + bad);
     } else if (!rows_diag) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int xr = 32 * (w - 2) + 16 * rt + lk + 4 * r, col = 16 * ct + li;
+                    if (xr < xrows && col < nb) Xg[(long)xr * lda + col] = acc[rt][ct][r];
+                }
+    }
+}
+
+// ---- Cholesky panel step, third design (round 2): a dedicated factor wave that runs one panel ahead -----------------------
+// In potrf_panel_mfma_kernel the 8-column panels are handed back and forth: wave 0 factors panel p, every wave subtracts it from the
+// tile that holds panel p+1 on the matrix cores, stages that panel, and wave 0 picks it up -- of the ~4700 cycles per panel only
+// ~2050 are the factorisation, ~1950 are that hand-over (LDS reads -> MFMAs -> accumulator read-back -> staging -> barrier).
+// Here a FIFTH wave does nothing but factor, in "lane = row" form, and applies panel p to panel p+1 ITSELF (8 x 8 multipliers read
+// with v_readlane, 128 FMAs per lane for the two row sets); the four tile waves keep the working set in MFMA accumulators as before
+// but only have to deliver panel p+1 updated THROUGH p-1 -- which they do while the factor wave is busy with panel p.  Per panel,
+// one workgroup barrier:
+//     factor wave : factor p (registers) -> F[p&1]            | tile waves: tile(p+1) -= panel p-1 (from F[(p-1)&1]); stage panel p+1
+//                                                             |             into Q[(p+1)&1]; other tiles -= panel p-1; keep final p-1
+//     ------------------------------------------------ barrier ------------------------------------------------
+//     factor wave : (a, x) <- Q[(p+1)&1] - (panel p) * (multipliers of rows 8(p+1) .. 8(p+1)+7)
+// Same contract as the other two panel kernels (load tickets, in-place store by one workgroup, pivots -> info).
+// MEASURED (tools/panel_stamp_probe.py) and NOT the default (gpk_debug_set(21, 2) selects it): 39.1 k cycles per 64 columns against 42.8 k
+// for the second design -- the factor wave needs 3000 (factor + store) + 490 (apply; 2200 when the multipliers came through
+// v_readlane instead of LDS broadcasts) per panel, but the tile waves now need 4000 for their share (update, stage, deferred updates,
+// final values: the same LDS -> MFMA -> LDS latency chains, merely moved), so they set the pace.  And with 218 VGPRs only ONE such
+// workgroup fits a CU: on the 32-CU chain partition the 63 workgroups of a panel run in two rounds (pipelined phase 3.55 -> 4.2 ms),
+// on the whole chip the Cholesky of Theta does not gain either (9.1 -> 9.5 ms).  Kept as the scaffold for a version whose tile waves
+// are relieved (8 of them, or the deferred updates moved behind the barrier with a third F buffer).
+__device__ __forceinline__ int lane_rows_factor8(double (&a)[8], double (&x)[8], int p, int l) {
+    int bad = 0;
+    const int cb = __builtin_amdgcn_readfirstlane(8 * p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int col = cb + j;
+        const double d = bcast_lane(a[j], col);                      // pivot (wave-uniform)
+        if (!(d > 0.0) && bad == 0) bad = col + 1;
+        const double y0 = __builtin_amdgcn_rsq(d);
+        double g = d * y0, hh = 0.5 * y0;
+        double e = fma(-g, hh, 0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        e = fma(-g, hh, 0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        const double sq = fma(fma(-g, g, d), hh, g);
+        const double rinv = hh + hh;
+        a[j] = (l == col) ? sq : a[j] * rinv;
+        x[j] = x[j] * rinv;
+#pragma unroll
+        for (int c = j + 1; c < 8; ++c) {
+            const double m = bcast_lane(a[j], cb + c);               // l[cb+c][col]
+            a[c] = fma(-a[j], m, a[c]);
+            x[c] = fma(-x[j], m, x[c]);
+        }
+    }
+    return bad;
+}
+
+__global__ __launch_bounds__(320) void potrf_panel_la_kernel(double* __restrict__ A, long lda, int nb, int below,
+                                                             int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
+    constexpr int PW = 8, PSW = PW + 2, KS = PW / 4, HPT = 16 / PW;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double Fb[2][128 * PSW];   // factored panels (rows 0..63: L, 64..127: X)
+    __shared__ __attribute__((aligned(16))) double Qb[2][128 * PSW];   // panels staged for the factor wave
+    __shared__ int sh_bad, sh_expired;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool fw = (w == 4);                                        // the factor wave
+    const int li = l & 15, lk = l >> 4;
+    // The workgroup that stores A_jj in place is the LAST one: it waits for the tickets of workgroups with smaller indices only,
+    // which the hardware dispatches first.  (With workgroup 0 in that role -- the first two designs -- a grid that is not fully
+    // resident can starve: on a CU-masked partition with one CU per shader engine, workgroup 32 is bound to the CU on which
+    // workgroup 0 spins.  Those kernels stay below the limit, 3 workgroups per CU; this one holds one per CU.)
+    const bool tall = blockIdx.x + 1 < gridDim.x;
+    const int c0 = (int)blockIdx.x * NB;
+    const int xrows = tall ? min(NB, below - c0) : 0;
+    double* __restrict__ Xg = A + (long)(nb + (tall ? c0 : 0)) * lda;
+    const bool rows_diag = (w < 2);
+    const bool active = !fw && (rows_diag || tall);
+    __builtin_amdgcn_s_setprio(3);
+    PANEL_STAMP(0);
+    if (tid == 0) sh_bad = 0;
+
+    d4 acc[2][4];
+    if (!fw) {
+        const double* __restrict__ base = (rows_diag || !tall) ? A : Xg;
+        const int rmax = (rows_diag || !tall) ? nb - 1 : xrows - 1;
+        const int rlim = rows_diag ? nb : xrows;
+        const int rbase = 32 * (w & 1) + lk;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
+                    acc[rt][ct][r] = base[(long)min(row, rmax) * lda + min(col, nb - 1)];
+                }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
+                    const double pad = (rows_diag && row == col) ? 1.0 : 0.0;
+                    acc[rt][ct][r] = (row < rlim && col < nb) ? acc[rt][ct][r] : pad;
+                }
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto stage = [&](double* __restrict__ P, int q, const d4 (&t0), const d4 (&t1)) {
+        if ((li / PW) == (q % HPT)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                P[(32 * w + lk + 4 * r) * PSW + (li % PW)] = t0[r];
+                P[(32 * w + 16 + lk + 4 * r) * PSW + (li % PW)] = t1[r];
+            }
+        }
+    };
+    auto update_static = [&](const double* __restrict__ P, auto lo_c, auto hi_c) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        double a0[KS], a1[KS], bf[4][KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            a0[ks] = -P[(32 * w + li) * PSW + 4 * ks + lk];
+            a1[ks] = -P[(32 * w + 16 + li) * PSW + 4 * ks + lk];
+        }
+#pragma unroll
+        for (int ct = LO; ct <= HI; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bf[ct][ks] = P[(16 * ct + li) * PSW + 4 * ks + lk];
+#pragma unroll
+        for (int ct = LO; ct <= HI; ++ct) {
+            if (16 * ct < nb) {
+                if (!rows_diag || 2 * w >= ct) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], bf[ct][ks], acc[0][ct], 0, 0, 0);
+                }
+                if (!rows_diag || 2 * w + 1 >= ct) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], bf[ct][ks], acc[1][ct], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto update_from = [&](const double* __restrict__ P, int lo, bool to_end) {
+        using std::integral_constant;
+        if (to_end) {
+            switch (lo) {
+                case 0: update_static(P, integral_constant<int, 0>{}, integral_constant<int, 3>{}); break;
+                case 1: update_static(P, integral_constant<int, 1>{}, integral_constant<int, 3>{}); break;
+                case 2: update_static(P, integral_constant<int, 2>{}, integral_constant<int, 3>{}); break;
+                case 3: update_static(P, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
+                default: break;
+            }
+        } else {
+            switch (lo) {
+                case 0: update_static(P, integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
+                case 1: update_static(P, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
+                case 2: update_static(P, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
+                case 3: update_static(P, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
+                default: break;
+            }
+        }
+    };
+    // final values of panel q (factored, in P) into my tiles
+    auto keep_final = [&](const double* __restrict__ P, int q) {
+        const int tq = q / HPT;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            if (ct == tq && (li / PW) == (q % HPT)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[0][ct][r] = P[(32 * w + lk + 4 * r) * PSW + (li % PW)];
+                    acc[1][ct][r] = P[(32 * w + 16 + lk + 4 * r) * PSW + (li % PW)];
+                }
+            }
+        }
+    };
+    const int npan = (nb + PW - 1) / PW;
+    if (active) stage(Qb[0], 0, acc[0][0], acc[1][0]);               // panel 0, raw
+    if (!fw && !active) {                                            // workgroup 0, waves 2-3: the extra rows are zero padding
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (li < PW) { Qb[0][(32 * w + lk + 4 * r) * PSW + li] = 0.0; Qb[0][(32 * w + 16 + lk + 4 * r) * PSW + li] = 0.0;
+                           Qb[1][(32 * w + lk + 4 * r) * PSW + li] = 0.0; Qb[1][(32 * w + 16 + lk + 4 * r) * PSW + li] = 0.0; }
+        }
+    }
+    __syncthreads();
+    if (tall && tid == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket: A_jj has been read
+    PANEL_STAMP(1);
+
+    double a[8], x[8];
+    if (fw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const d2 t = *reinterpret_cast<const d2*>(Qb[0] + l * PSW + 2 * i);
+            a[2 * i] = t.x; a[2 * i + 1] = t.y;
+            const d2 u = *reinterpret_cast<const d2*>(Qb[0] + (64 + l) * PSW + 2 * i);
+            x[2 * i] = u.x; x[2 * i + 1] = u.y;
+        }
+    }
+#pragma unroll 1
+    for (int p = 0; p < npan; ++p) {
+        double* __restrict__ Fc = Fb[p & 1];
+        const double* __restrict__ Fp = Fb[(p + 1) & 1];             // factored panel p-1
+        double* __restrict__ Qn = Qb[(p + 1) & 1];                   // panel p+1 for the factor wave
+        if (p == 2) PANEL_STAMP(3);
+        if (fw) {
+            if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[8] = clock64();
+            const int bad = lane_rows_factor8(a, x, p, l);
+            if (bad && l == 0 && sh_bad == 0) sh_bad = bad;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<d2*>(Fc + l * PSW + 2 * i) = (d2){a[2 * i], a[2 * i + 1]};
+                *reinterpret_cast<d2*>(Fc + (64 + l) * PSW + 2 * i) = (d2){x[2 * i], x[2 * i + 1]};
+            }
+            if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[9] = clock64();
+        } else if (active) {
+            const int tn = (p + 1) / HPT;
+            if (p > 0) {
+                if (p + 1 < npan) update_from(Fp, tn, false);        // the tile with panel p+1 first
+            }
+            if (p + 1 < npan) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    if (ct == tn) stage(Qn, p + 1, acc[0][ct], acc[1][ct]);
+            }
+            if (p > 0) {
+                if (p + 1 < npan) update_from(Fp, tn + 1, true);     // the tiles further right
+                keep_final(Fp, p - 1);
+            }
+        }
+        if (p == 2) PANEL_STAMP(4);
+        __syncthreads();
+        if (p == 2) PANEL_STAMP(5);
+        if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[10] = clock64();
+        if (fw && p + 1 < npan) {
+            double an[8], xn[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const d2 t = *reinterpret_cast<const d2*>(Qn + l * PSW + 2 * i);
+                an[2 * i] = t.x; an[2 * i + 1] = t.y;
+                const d2 u = *reinterpret_cast<const d2*>(Qn + (64 + l) * PSW + 2 * i);
+                xn[2 * i] = u.x; xn[2 * i + 1] = u.y;
+            }
+            // the 8 x 8 multipliers L[8(p+1)+c][8p+j] come back from F as LDS broadcast reads (every lane the same address): as
+            // 128 v_readlane the step took 2200 cycles, more than the factorisation
+            const int cn = __builtin_amdgcn_readfirstlane(8 * (p + 1));
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                double m[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const d2 t = *reinterpret_cast<const d2*>(Fc + (cn + c) * PSW + 2 * i);
+                    m[2 * i] = t.x; m[2 * i + 1] = t.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    an[c] = fma(-a[j], m[j], an[c]);
+                    xn[c] = fma(-x[j], m[j], xn[c]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { a[c] = an[c]; x[c] = xn[c]; }
+            if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[11] = clock64();
+        }
+        if (p == 2) PANEL_STAMP(6);
+    }
+    if (active) keep_final(Fb[(npan - 1) & 1], npan - 1);            // (written before the loop's last barrier)
+    PANEL_STAMP(2);
+
+    if (!tall) {
+        __syncthreads();
+        if (tid == 0) {
+            int it = 0, ex = 0;
+            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++it > (1 << 24)) { ex = 1; break; }
+            }
+            sh_expired = ex;
+        }
+        __syncthreads();
+        if (sh_expired) {
+            if (tid == 0) atomicCAS(info, 0, -1);
+            return;
+        }
+        if (rows_diag) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 32 * w + 16 * rt + lk + 4 * r, col = 16 * ct + li;
+                        if (row < nb && col <= row) A[(long)row * lda + col] = acc[rt][ct][r];
+                    }
+        }
+        const int bad = sh_bad;
+        if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, pivot_base + bad);
+    } else if (!rows_diag && !fw) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1505,7 +1817,10 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
         if (g_fused_panel) {
             const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
             const unsigned target = h->panel_loaded + (unsigned)nrb;
-            if (g_panel_mfma)
+            if (g_panel_mfma == 2)
+                potrf_panel_la_kernel<<<1 + nrb, 320, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+            else if (g_panel_mfma)
                 potrf_panel_mfma_kernel<8><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                             (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
             else

@@ -2,7 +2,7 @@
 """What happens to the two-partition pipeline when the process already owns other streams (torch's stream pool): runs Gauss-Newton
 steps at n_z = 1100 on a fresh context after creating torch streams, reports whether the pipeline stayed on, the handle's message
 and the step time.  Usage: alias_probe.py [n_torch_streams [n_raw_hip_streams]]"""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, 'nonlinpdes-gpsolver_amd')
 sys.path.insert(0, '.')
@@ -23,7 +23,7 @@ if nraw:
     for r in raw:
         assert hip.hipStreamCreateWithFlags(ctypes.byref(r), 1) == 0
 rng = np.random.RandomState(3)
-Nd, Nb = 2000, 200
+Nd, Nb = int(os.environ.get("PROBE_ND", "2000")), 200
 Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
 f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
 T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-10, 'adaptive')

@@ -18,4 +18,5 @@ for rep in range(4):
     print('panel kernel (last launch with >= 2 workgroups), workgroup 1: stage %d cycles, potf2_tile<TALL> %d cycles' % (s[1] - s[0], s[2] - s[1]))
     print('   second design, panel 2 (thread 0 = wave 0): factor %d | wait for barrier B %d | update+reload+stage %d | to barrier B of panel 3 %d' % (
         s[4] - s[3], s[5] - s[4], s[6] - s[5], s[7] - s[6]))
+    print('   third design: tile wave 0 work %d | barrier wait %d ; factor wave: factor+store %d | wait %d | apply %d' % (s[4] - s[3], s[5] - s[4], s[9] - s[8], s[10] - s[9], s[11] - s[10]))
 ctx.lib.gpk_debug_stamps(ctx.h, None, 0)
