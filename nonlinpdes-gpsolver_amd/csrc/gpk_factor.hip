@@ -1900,7 +1900,7 @@ int g_pipeline_chain_cus = 32;                                       // gpk_debu
 int g_pipeline_pre = 1;                                              // gpk_debug_set key 17: blocks of the product computed before the fork
 int g_pipeline_lookahead = 0;                                        // gpk_debug_set key 26: 0 = block j's update with block j-1 as ONE product after the chain of j-1
 int g_pipeline_units = 1000;                                          // gpk_debug_set key 24: workgroups aimed at per product launch of the pipeline (split-K; 0 = no split).  Measured at config 2, phase time: 0 / 1000 / 1500 / 2000 / 3000 -> 3.85 / 3.57 / 3.58 / 3.60 / 3.62 ms
-int g_pipeline_max_n = 5000;                                         // gpk_debug_set key 14: pipelined only up to this order
+int g_pipeline_max_n = 7000;                                         // gpk_debug_set key 14: pipelined only up to this order (with the split-K products, product + factorisation per step: order 6001 7.18 -> 6.50 ms, 7001 13.7 -> 13.6, 8501 22.3 -> 23.3, 10001 35.8 -> 38.6)
 
 // Block columns of the pipelined factorisation: a first block of g_pipeline_w0 columns (the chain can only start once its product is
 // there), then blocks of g_pipeline_ob columns; widths are multiples of the panel width, at most 512.

@@ -35,7 +35,7 @@ VARIANTS = [
     ('look-ahead, narrow first block, 256-column blocks', {26: 1, 28: 128, 29: 256}),
     ('192-column blocks, right-looking chain, look-ahead', {26: 1, 28: 64, 29: 192, 18: 0}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 5000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
