@@ -53,6 +53,7 @@ struct GemmArgs {
     int vecA, vecB;
     int ntm, ntn, ntiles;
     int ntm_full;      // tri_a: number of row tiles of C (ntm counts PAIRS of them then)
+    int band;          // > 0: leading-zero launches are ordered in bands of this many row tiles (see map_tile)
     int nsuper;        // > 0: supertile schedule of the lower-triangular, leading-zero (SYRK) launch, see map_tile
     int splitk;        // > 1: every tile's K range is cut into `splitk` chunks, one workgroup each (blockIdx = tile * splitk + chunk);
                        // the chunks leave their accumulators in `ws`, take a ticket in cnt[tile], and the LAST arriver adds them up in
@@ -118,6 +119,7 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
 int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
+int g_band_mb = 128;                                                 // gpk_debug_set key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
 int g_tall_min = 1500;                                               // gpk_debug_set key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
 int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
 int g_rev_k = 0;                                                     // gpk_debug_set key 16
@@ -173,8 +175,21 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
             tm = i; tn = logical - i * (i + 1) / 2;
         }
     } else if (g.lead > 0) {
-        tn = g.ntn - 1 - b / g.ntm;                                   // column-major from the longest column, as above
-        tm = b % g.ntm;
+        if (g.band > 0) {
+            // tall launches: bands of `band` row tiles, column-major from the longest column INSIDE a band -- the band's rows of A
+            // (band * BM * K * 8 bytes, kept below ~100 MB) stay in the 256 MB Infinity Cache while the band sweeps the columns,
+            // instead of the whole of A being streamed from HBM once per column tile (north-star size: 157 times 856 MB)
+            const int per = g.band * g.ntn;
+            const int bd = b / per;
+            const int r0 = bd * g.band;
+            const int rows = min(g.band, g.ntm - r0);
+            const int rem = b - bd * per;
+            tn = g.ntn - 1 - rem / rows;
+            tm = r0 + rem % rows;
+        } else {
+            tn = g.ntn - 1 - b / g.ntm;                               // column-major from the longest column, as above
+            tm = b % g.ntm;
+        }
     } else {
         constexpr int GROUP = 8;
         const int per_group = GROUP * g.ntn;
@@ -547,6 +562,14 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         for (int cg = 0; cg < ncg; ++cg) g.nsuper += gpk_ceil_div(T - cg * SG_W, SG_H);
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
     }
+    g.band = 0;
+    if (g.lead > 0 && !g.lower_only && !g.tri_a && g_band_mb > 0) {
+        const double panel = (double)BM * g.K * sizeof(double);       // one row tile's rows of A
+        if ((double)g.ntm * panel > 2.0 * g_band_mb * 1048576.0) {
+            int r = (int)(g_band_mb * 1048576.0 / panel);
+            g.band = r < 1 ? 1 : r;
+        }
+    }
     g.splitk = 1; g.ws = nullptr; g.cnt = nullptr;
     int want = h->splitk_req;
     if (want <= 1 && g_force_splitk > 1 && gpk_i_splitk_reserve(h) == 0) want = g_force_splitk;
@@ -634,6 +657,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 16) { g_rev_k = value; return 0; }
     if (key == 25) { g_force_splitk = value; return 0; }
     if (key == 33) { g_tall_min = value; return 0; }
+    if (key == 35) { g_band_mb = value; return 0; }
     return GPK_ERR_ARG;
 }
 
