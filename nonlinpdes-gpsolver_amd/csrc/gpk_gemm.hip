@@ -119,7 +119,8 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
 int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
-int g_band_mb = 128;                                                 // gpk_debug_set key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
+int g_band_mb = 192;                                                 // gpk_debug_set key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
+int g_syrk_band = 256;                                               // gpk_debug_set key 36: MB of S per band of a large leading-zero SYRK launch (0 = column-major over all rows).  North-star size, the product S^T S: no bands 24.15 ms, 192 MB 23.4, 256 MB 22.9, 384 MB 23.55, 512 MB 24.3
 int g_tall_min = 1500;                                               // gpk_debug_set key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
 int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
 int g_rev_k = 0;                                                     // gpk_debug_set key 16
@@ -166,7 +167,30 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
         int i = (int)((sqrt(8.0 * (double)logical + 1.0) - 1.0) * 0.5);
         while ((long)(i + 1) * (i + 2) / 2 <= logical) ++i;
         while ((long)i * (i + 1) / 2 > logical) --i;
-        if (g.lead > 0) {
+        if (g.lead > 0 && g.band > 0) {
+            // large products: bands of `band` tile rows from the bottom; inside a band column-major from the longest column (first
+            // the band's own triangle, then the full columns to its left).  The band's `band` column panels of S stay in the
+            // Infinity Cache while the band sweeps the other panels, instead of every column sweeping all panels below it.
+            const int T = g.ntm, R = g.band;
+            int r1 = T, rem = b;
+            for (;;) {                                                // (at most T / R iterations, scalar)
+                const int r0b = max(r1 - R, 0);
+                const int cnt = r1 * (r1 + 1) / 2 - r0b * (r0b + 1) / 2;
+                if (rem < cnt || r0b == 0) break;
+                rem -= cnt; r1 = r0b;
+            }
+            const int r0 = max(r1 - R, 0), rows = r1 - r0;
+            const int tri = rows * (rows + 1) / 2;
+            if (rem < tri) {                                          // triangle: column r1-1-c holds rows r1-1-c .. r1-1
+                int c = (int)((sqrt(8.0 * (double)rem + 1.0) - 1.0) * 0.5);
+                while ((c + 1) * (c + 2) / 2 <= rem) ++c;
+                while (c * (c + 1) / 2 > rem) --c;
+                tn = r1 - 1 - c; tm = tn + (rem - c * (c + 1) / 2);
+            } else {
+                const int q = rem - tri;
+                tn = r0 - 1 - q / rows; tm = r0 + q % rows;
+            }
+        } else if (g.lead > 0) {
             // leading zeros: work depends on the column block only.  Column-major from the right-most (longest) column:
             // strictly longest-first, and the tiles of a column -- same K range, dispatched back to back, every 8th on
             // the same XCD -- walk their shared column panel in step (L2 reuse without a static per-XCD partition).
@@ -563,6 +587,13 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
     }
     g.band = 0;
+    if (g.lead > 0 && g.lower_only && g_syrk_band > 0) {
+        const double panel = (double)BM * g.K * sizeof(double);       // one column panel of S
+        if ((double)g.ntm * panel > 4.0 * g_syrk_band * 1048576.0) {
+            int r = (int)(g_syrk_band * 1048576.0 / panel);
+            g.band = r < 2 ? 2 : r;
+        }
+    }
     if (g.lead > 0 && !g.lower_only && !g.tri_a && g_band_mb > 0) {
         const double panel = (double)BM * g.K * sizeof(double);       // one row tile's rows of A
         if ((double)g.ntm * panel > 2.0 * g_band_mb * 1048576.0) {
@@ -658,6 +689,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 25) { g_force_splitk = value; return 0; }
     if (key == 33) { g_tall_min = value; return 0; }
     if (key == 35) { g_band_mb = value; return 0; }
+    if (key == 36) { g_syrk_band = value; return 0; }
     return GPK_ERR_ARG;
 }
 
