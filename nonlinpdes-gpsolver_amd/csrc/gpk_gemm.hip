@@ -215,7 +215,7 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
             tm = b % g.ntm;
         }
     } else {
-        constexpr int GROUP = 8;
+        constexpr int GROUP = 8;                                     // (4 / 16 / 32 measured at the north-star size: no difference)
         const int per_group = GROUP * g.ntn;
         const int gid = logical / per_group;
         const int first = gid * GROUP;
@@ -707,6 +707,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.stagger = g_stagger;
+    g.band = 0; g.splitk = 1; g.ws = nullptr; g.cnt = nullptr; g.nsuper = 0; g.ntm_full = 0;   // (set per launch configuration below)
     g.rev_k = (g_rev_k && g.lead > 0) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
