@@ -121,6 +121,7 @@ int g_gemm_extra_lds = 0;                                            // gpk_debu
 int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
 int g_band_mb = 192;                                                 // gpk_debug_set key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
 int g_syrk_band = 256;                                               // gpk_debug_set key 36: MB of S per band of a large leading-zero SYRK launch (0 = column-major over all rows).  North-star size, the product S^T S: no bands 24.15 ms, 192 MB 23.4, 256 MB 22.9, 384 MB 23.55, 512 MB 24.3
+int g_big_min = 6000;                                                 // gpk_debug_set key 38: launches with at least this many 64 x 64 tiles use the 128 x 128 tile with 16 waves, one workgroup per CU (0 = never).  tools/gemm_big_probe.py, 64 x 64 -> 128 x 64 -> this: NN 10500^3 60.0 / 58.6 / 65.2 TF/s, 8192^3 62.2 / 60.9 / 69.1 on a slow box; north-star solve phase 44.6 -> 43.7 ms with thresholds 3000 .. 6000; at config 2 (threshold 2000) the solve phase loses 5 %
 int g_tall_min = 1500;                                               // gpk_debug_set key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
 int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
 int g_rev_k = 0;                                                     // gpk_debug_set key 16
@@ -228,12 +229,12 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
 }
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool TRI = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 2) void gemm_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) >= 16 ? 1 : 2)) void gemm_f64_kernel(GemmArgs g) {
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;                   // threads: 4 waves, or 8 for the 128 x 64 tile
-    constexpr bool PF2 = (BM * BN <= 64 * 64) || NT == 512;                     // prefetch depth 2 for the small-tile configuration
+    constexpr bool PF2 = (BM * BN <= 64 * 64) || NT >= 512;                     // prefetch depth 2 for the small-tile configuration
     constexpr int WAVES_N = BN / WN;
-    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
+    static_assert(NT == 256 || NT == 512 || NT == 1024, "4, 8 or 16 waves per workgroup");
     constexpr int A_SZ = TA ? BK * (BM + 16) : BM * (BK + 2);
     constexpr int B_SZ = TB ? BN * (BK + 2) : BK * (BN + 16);
     __shared__ __attribute__((aligned(16))) double smem[2 * (A_SZ + B_SZ)];
@@ -689,6 +690,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 25) { g_force_splitk = value; return 0; }
     if (key == 33) { g_tall_min = value; return 0; }
     if (key == 35) { g_band_mb = value; return 0; }
+    if (key == 38) { g_big_min = value; return 0; }
     if (key == 36) { g_syrk_band = value; return 0; }
     return GPK_ERR_ARG;
 }
@@ -720,6 +722,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
     const bool big = (g_force_cfg == 1) && !g.tri_a;
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
+    if ((g_force_cfg == 4 || (g_force_cfg == 0 && g_big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_big_min)) && !g.tri_a && !lower_only)
+        return launch_cfg<128, 128, 32, 32>(h, ta, tb, g);           // 16 waves, one workgroup per CU
     if ((g_force_cfg == 3 || (g_force_cfg == 0 && g_tall_min > 0 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_tall_min)) && !g.tri_a && !lower_only)
         return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);            // 8 waves, 2 workgroups per CU
     // short-and-wide updates of the triangular-solve recursion (M = 256 or 512 against ~4000 columns): 64x64 tiles give

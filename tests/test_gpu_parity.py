@@ -120,11 +120,11 @@ def test_gemm(ctx, ta, tb, m, n, k):
     assert np.max(np.abs(got - want)) <= bound
 
 
-@pytest.mark.parametrize('cfg', [1, 2, 3])
+@pytest.mark.parametrize('cfg', [1, 2, 3, 4])
 @pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize('m,n,k', [(130, 70, 33), (257, 513, 100), (1, 7, 5), (700, 900, 129), (128, 64, 16)])
 def test_gemm_forced_tile_configurations(ctx, cfg, ta, tb, m, n, k):
-    """gpk_debug_set(0, c): 128x128 tiles, 64x64 tiles, and the 128x64 tile with 8 waves (the one large launches take by default) on
+    """gpk_debug_set(0, c): 128x128 tiles (4 waves), 64x64 tiles, the 128x64 tile with 8 waves and the 128x128 tile with 16 waves (large launches) on
     ragged shapes -- every instantiation of the kernel template is exercised whatever the size heuristics pick"""
     rng = np.random.RandomState(m + n + k + cfg)
     A = rng.normal(size=(k, m) if ta else (m, k))

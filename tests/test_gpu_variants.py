@@ -18,7 +18,8 @@ VARIANTS = [
     ('supertile schedule of the leading-zero SYRK', {6: 1}),
     ('128x128 GEMM tiles', {0: 1}),
     ('128x64 tiles with 8 waves for every launch', {0: 3}),
-    ('64x64 tiles also for the large launches', {33: 0}),
+    ('64x64 tiles also for the large launches', {33: 0, 38: 0}),
+    ('128x128 tiles with 16 waves for every launch', {0: 4}),
     ('leading-zero launches in bands of 1 MB of A (every launch banded)', {35: 1, 36: 1}),
     ('no banded tile orders', {35: 0, 36: 0}),
     ('persistent outer-block Cholesky kernel (flag-chained workgroups)', {7: 1}),
@@ -37,7 +38,7 @@ VARIANTS = [
     ('look-ahead, narrow first block, 256-column blocks', {26: 1, 28: 128, 29: 256}),
     ('192-column blocks, right-looking chain, look-ahead', {26: 1, 28: 64, 29: 192, 18: 0}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500, 35: 192, 36: 256}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500, 35: 192, 36: 256, 38: 6000}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
