@@ -466,7 +466,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
     # one-time companion of the factor: inverses of its 1024-row diagonal blocks (the column solves then are GEMMs only);
     # S2 receives the solved block out of place and is zero where the solve never writes
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    Dinv = ops.trtri_diag(Theta, N, block=gpk.device.DINV_BLOCK or 1024)
+    Dinv = ops.trtri_diag(Theta, N, block=gpk.device.dinv_block_for(N))
     torch.cuda.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
     S2 = torch.zeros((N, lds), dtype=torch.float64, device=dev)
     losses = []
@@ -505,7 +505,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
                        'parallelism': f'Theta: panel-sharded Cholesky (block-cyclic columns, width {args.panel}, RCCL broadcast); step: '
-                                      f'column-sharded TRSM (GEMM-only, inverted 1024-row diagonal blocks of the factor) + all-gather(S) + row-block-sharded SYRK + all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)',
+                                      f'column-sharded TRSM (GEMM-only, inverted {gpk.device.dinv_block_for(N)}-row diagonal blocks of the factor) + all-gather(S) + row-block-sharded SYRK + all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)',
                        'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step, nothing cached across steps); structural zeros of A(z) '
                                       'skipped as on one GPU, column shards cut by work; f1_tflops is the dense-equivalent rate'},
             'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': warmup + steps,
