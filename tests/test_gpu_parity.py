@@ -235,6 +235,35 @@ def test_potrf(ctx, n):
     assert np.linalg.norm(L - Lref) <= 1e-11 * np.linalg.norm(Lref)
 
 
+@pytest.mark.parametrize('panel', [1, 2])
+def test_potrf_grid_larger_than_resident(ctx, panel):
+    """Panel kernels with more workgroups than the chip holds at once (the third design keeps one workgroup per CU: 261 > 256): the
+    workgroup that stores the diagonal block waits for the others' load tickets, so it must be one that is dispatched AFTER them (a
+    wait for a later workgroup starves when that workgroup is bound to the waiting one's CU).  Checked through sampled entries of L L^T."""
+    n, k = 16640, 48
+    rng = np.random.RandomState(3)
+    M = rng.normal(size=(k, n))
+    dM = ctx.array(M)
+    dA = ctx.empty(n, n)
+    ctx.syrk(n, k, 1.0, dM, 0.0, dA, full=True)
+    A = dA.download()
+    A[np.arange(n), np.arange(n)] += n
+    dA.upload(A)
+    ctx.lib.gpk_debug_set(21, panel)
+    try:
+        info = ctx.potrf(dA)
+    finally:
+        ctx.lib.gpk_debug_set(21, 1)
+    assert info == 0
+    L = np.tril(dA.download())
+    ii = rng.randint(0, n, 64); jj = rng.randint(0, n, 64)
+    for i, j in zip(ii, jj):
+        assert abs(L[i] @ L[j] - A[i, j]) <= 1e-12 * n
+    rows = rng.randint(0, n, 4)
+    assert np.max(np.abs(L[rows] @ L.T - A[rows])) <= 1e-12 * n
+    dA.free(); dM.free()
+
+
 def test_potrf_reports_first_bad_pivot(ctx):
     rng = np.random.RandomState(1)
     n = 300
