@@ -148,3 +148,30 @@ def test_cholesky_more_row_blocks_than_resident_workgroups():
     assert np.all(np.isfinite(xh))
     assert np.linalg.norm(Lh @ xh - b) <= 1e-12 * np.linalg.norm(Lh) * np.linalg.norm(xh)   # backward-stable substitution
     ctx.close()
+
+
+def test_config2_steps_are_bitwise_reproducible(setup):
+    """The same Gauss-Newton steps from the same start, repeated: split-K reductions (the last arriver adds the chunks in chunk
+    order), the two-partition pipeline and the flag-chained triangular solves must not make the bits depend on the order in which
+    workgroups happen to arrive (tools/determinism_probe.py runs 30 repeats)."""
+    import gpk
+    ctx, Xd, Xb = setup
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', SIGMA, Xd, Xb, 1e-13, 'adaptive')
+    assert ctx.potrf(T) == 0
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', ND, NB_, f, g, T, p0=1.0, p1=3.0)
+    init = np.random.RandomState(4).normal(size=ND)
+    ref = None
+    for _ in range(6):
+        z = ctx.array(init)
+        losses = []
+        for _ in range(4):
+            loss, info = ctx.gn_step(prob, z, 1.0)
+            assert info == 0
+            losses.append(loss)
+        out = z.download().ravel().copy()
+        z.free()
+        if ref is None:
+            ref = (out, losses)
+        else:
+            assert np.array_equal(out, ref[0]) and losses == ref[1]
