@@ -143,6 +143,8 @@ typedef struct {
     const double* Dinv;            /* optional (may be NULL): gpk_trtri_diag(L)  -- the S solve then runs as GEMMs only */
     const double* Dinv2;           /* optional, DARCY: gpk_trtri_diag(L2) */
     int dinv_block;                /* block size Dinv / Dinv2 were built with (0 = 256) */
+    /* optional (may be NULL), GPK_GN_ELLIPTIC only -- see gpk_gn_structured_prepare */
+    const double* W1; const double* W2; const double* v0; int ldw;
 } gpk_gn_problem;
 
 /* sizes: nz unknowns, rows of the stacked S = [L^{-1}A | L^{-1}F] buffer */
@@ -156,6 +158,14 @@ int gpk_gn_dims(const gpk_gn_problem* host_prob, int* nz, int* s_rows);
  * host_loss_in = loss(z_in); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g. */
 int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double step_size,
                 double* S, int lds, double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);
+/* OPTIONAL structured solve of the elliptic system (not what the reference does per step; off unless W1/W2/v0 are set).  A(z) =
+ * [diag(alpha m z^(m-1)); I; 0] has its non-zeros in fixed places and the solve is linear in the right-hand sides, so with
+ *   W1 = L^{-1} [I; 0; 0],  W2 = L^{-1} [0; I; 0]   (s_rows x nz each, leading dimension ldw >= nz+1, columns in the internal order of
+ *   gpk_gn_step),  v0 = L^{-1} F(0)  (s_rows)
+ * computed ONCE by this call (two solves; S is scratch, s_rows x lds), every later gpk_gn_step whose host_prob carries W1, W2, v0, ldw
+ * forms  S = [W1 diag(d(z)) + W2 | v0 + W1 (alpha z^m) + W2 z]  in one memory-bound pass instead of the triangular solve.  Same
+ * iterates up to rounding (tests/test_gpu_structured.py); the product, the factorisation and the update are unchanged. */
+int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* S, int lds, double* W1, double* W2, double* v0, int ldw);
 /* building blocks of gpk_gn_step for the column-sharded multi-GPU step: S <- [A(z) | F(z)] (no solve), y += alpha x */
 int gpk_gn_build(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* S, int lds);
 /* Same with unknown j stored in column n_z-1-j (elliptic system only): column c < n_z of [A | F] is then zero above row

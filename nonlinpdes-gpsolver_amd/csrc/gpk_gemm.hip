@@ -656,6 +656,7 @@ extern "C" int gpk_debug_set_pipeline_pre(int v);
 extern "C" int gpk_debug_set_pipeline_units(int v);
 extern "C" int gpk_debug_set_pipeline_lookahead(int v);
 extern "C" int gpk_debug_set_solve_splitk(int v);
+extern "C" int gpk_debug_set_structured(int v);
 extern "C" int gpk_debug_set_pipeline_widths(int key, int v);
 extern "C" int gpk_debug_set_left_looking_panels(int v);
 extern "C" int gpk_debug_set_potrf_pipeline(int key, int v);
@@ -682,6 +683,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 24) return gpk_debug_set_pipeline_units(value);
     if (key == 26) return gpk_debug_set_pipeline_lookahead(value);
     if (key == 30) return gpk_debug_set_solve_splitk(value);
+    if (key == 40) return gpk_debug_set_structured(value);
     if (key == 28 || key == 29) return gpk_debug_set_pipeline_widths(key, value);
     if (key == 18) return gpk_debug_set_left_looking_panels(value);
     if (key == 19 || key == 20) return gpk_debug_set_potrf_pipeline(key, value);

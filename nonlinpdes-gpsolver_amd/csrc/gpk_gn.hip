@@ -56,6 +56,8 @@ struct BuildArgs {
                        // unknowns of point t (columns t, N_d + t, 2 N_d + t all start in row t) interleaved: pos(j) = 3t + group,
                        // a staircase of slope 1/3 (column zero above row pos/3; gpk_ctx::lead_div = 3)
     int nz;
+    int family;        // elliptic system, gpk_gn_structured_prepare: 1 = only the unit entries of the first row group ([I; 0; 0], no F),
+                       // 2 = only those of the second ([0; I; 0]) together with F(z); 0 = the normal [A(z) | F(z)]
 };
 
 // position of unknown j in the staircase order (see BuildArgs::rev)
@@ -75,9 +77,11 @@ __global__ __launch_bounds__(256) void gn_build_kernel(BuildArgs a) {
     const double* z = a.z;
     if (a.system == GPK_GN_ELLIPTIC) {                      // src/PDEs.py:84-85 (F), :95-96 (A)
         const double alpha = a.p0, m = a.p1;
-        if (t < Nd) {
+        if (a.family == 1) {
+            if (t < Nd) putA(a, t, t, 1.0);
+        } else if (t < Nd) {
             const double zi = z[t];
-            putA(a, t, t, alpha * m * pow(zi, m - 1.0));
+            if (a.family == 0) putA(a, t, t, alpha * m * pow(zi, m - 1.0));
             putA(a, Nd + t, t, 1.0);
             putF(a, t, alpha * pow(zi, m) - a.f[t]);
             putF(a, Nd + t, zi);
@@ -160,9 +164,9 @@ __global__ void scale_kernel(int n, double alpha, double* __restrict__ x) {
     if (i < n) x[i] *= alpha;
 }
 
-int build(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, long lds, int fcol, int write_A, int rev = 0) {
+int build(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, long lds, int fcol, int write_A, int rev = 0, int family = 0) {
     BuildArgs a;
-    a.rev = rev; a.nz = fcol;
+    a.rev = rev; a.nz = fcol; a.family = family;
     a.system = p->system; a.Nd = p->Nd; a.Nb = p->Nb; a.Ndata = p->Ndata;
     a.p0 = p->p0; a.p1 = p->p1; a.lam = p->pen_lambda;
     a.f = p->rhs_f; a.gb = p->bdy_g; a.data = p->data_u; a.z = z;
@@ -191,7 +195,7 @@ int g_eikonal_lz = 1;                // gpk_debug_set key 23: 0 = dense schedule
 // With the inverses of the diagonal blocks of every factor at hand (gpk_trtri_diag, gpk_gn_problem::Dinv) the solve runs
 // out of place into the handle's workspace W (all-GEMM, see gpk_i_trsm_left_dinv) and the SYRK reads W; S is scratch then.
 int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, double* S, int lds,
-                              double* Hb, int ldh, double alpha, int rev, double** Wout = nullptr) {
+                              double* Hb, int ldh, double alpha, int rev, double** Wout = nullptr, int family = 0) {
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
     bool dinv = g_use_dinv != 0;
@@ -211,7 +215,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
     }
     GPK_PROF_MARK(h, 0);
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
-    GPK_TRY(build(h, p, z, S, lds, d.nz, 1, rev));
+    GPK_TRY(build(h, p, z, S, lds, d.nz, 1, rev, family));
     for (int k = 0; k < d.ngroups; ++k) {
         const Group& g = d.g[k];
         double* Sg = S + (long)g.off * lds;
@@ -234,7 +238,83 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
     return 0;
 }
 
+// ---- structured solve of the elliptic system (optional, gpk_gn_structured_prepare) -------------------------------------------
+// per-column coefficients in the internal (reversed) column order: column c holds unknown u = nz-1-c
+__global__ void structured_coeff_kernel(int nz, double alpha, double m, const double* __restrict__ z, double* __restrict__ dcol,
+                                        double* __restrict__ acol, double* __restrict__ zcol) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= nz) return;
+    const double zi = z[nz - 1 - c];
+    dcol[c] = alpha * m * pow(zi, m - 1.0);
+    acol[c] = alpha * pow(zi, m);
+    zcol[c] = zi;
+}
+
+// one workgroup per row r: S[r][c] = d[c] W1[r][c] + W2[r][c] (c < nz), S[r][nz] = v0[r] + sum_c (a[c] W1[r][c] + z[c] W2[r][c]).
+// Columns left of the leading-zero boundary (c < nz-1-r) are zero in W1, W2 and are written as zeros.
+__global__ __launch_bounds__(256) void structured_form_kernel(int nz, const double* __restrict__ W1, const double* __restrict__ W2, long ldw,
+                                                              const double* __restrict__ v0, const double* __restrict__ dcol,
+                                                              const double* __restrict__ acol, const double* __restrict__ zcol,
+                                                              double* __restrict__ S, long lds) {
+    __shared__ double red[4];
+    const long r = blockIdx.x;
+    const double* w1 = W1 + r * ldw;
+    const double* w2 = W2 + r * ldw;
+    double* s = S + r * lds;
+    const int cz = (int)max(0L, (long)nz - 1 - r) & ~1;             // first column that can be non-zero (even: 16-byte pairs)
+    double acc = 0.0;
+    for (int c = 2 * (int)threadIdx.x; c < nz; c += 512) {
+        if (c + 1 < cz) { s[c] = 0.0; s[c + 1] = 0.0; continue; }
+        const double a0 = w1[c], b0 = w2[c];
+        s[c] = fma(dcol[c], a0, b0);
+        acc = fma(acol[c], a0, fma(zcol[c], b0, acc));
+        if (c + 1 < nz) {
+            const double a1 = w1[c + 1], b1 = w2[c + 1];
+            s[c + 1] = fma(dcol[c + 1], a1, b1);
+            acc = fma(acol[c + 1], a1, fma(zcol[c + 1], b1, acc));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) s[nz] = v0[r] + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ void sub_kernel(long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] - b[i];
+}
+
+int g_structured = 1;                // gpk_debug_set key 40: 0 = ignore W1/W2/v0 (always the triangular solve)
+
 }  // namespace
+
+extern "C" int gpk_debug_set_structured(int v) { g_structured = v; return 0; }
+
+extern "C" int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* p, double* S, int lds, double* W1, double* W2, double* v0, int ldw) {
+    if (!h || !S || !W1 || !W2 || !v0) return GPK_ERR_ARG;
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    if (p->system != GPK_GN_ELLIPTIC) return gpk_bad_arg(h, "structured solve: elliptic system only");
+    const int nc = d.nz + 1;
+    if (lds < nc || ldw < nc) return gpk_bad_arg(h, "structured solve: lds/ldw < nz+1");
+    double* zero = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&zero, (size_t)d.nz * sizeof(double)));
+    hipError_t e = hipMemsetAsync(zero, 0, (size_t)d.nz * sizeof(double), h->stream);
+    int rc = e == hipSuccess ? 0 : gpk_fail(h, e, "hipMemsetAsync", __FILE__, __LINE__);
+    for (int fam = 1; fam <= 2 && rc == 0; ++fam) {                  // [I; 0; 0] -> W1;  [0; I; 0] with F(0) -> W2, v0
+        double* W = nullptr;
+        rc = assemble_normal_equations(h, p, d, zero, S, lds, nullptr, nc, 1.0, 1, &W, fam);   // (no product: Wout is set)
+        if (rc) break;
+        e = hipMemcpy2DAsync(fam == 1 ? W1 : W2, (size_t)ldw * 8, W, (size_t)lds * 8, (size_t)nc * 8, d.rows, hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess && fam == 2)
+            e = hipMemcpy2DAsync(v0, 8, W + d.nz, (size_t)lds * 8, 8, d.rows, hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) rc = gpk_fail(h, e, "hipMemcpy2DAsync", __FILE__, __LINE__);
+    }
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(zero);
+    return rc;
+}
 
 extern "C" int gpk_gn_dims(const gpk_gn_problem* p, int* nz, int* s_rows) {
     Dims d;
@@ -261,7 +341,19 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         gpk_handle h; explicit SlopeGuard(gpk_handle hh, int s) : h(hh) { h->lead_div = s; } ~SlopeGuard() { h->lead_div = 1; }
     } slope_guard(h, rev == 3 ? 3 : 1);
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
-    GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
+    if (g_structured && p->system == GPK_GN_ELLIPTIC && p->W1 && p->W2 && p->v0 && p->ldw >= nz + 1) {
+        // optional structured solve (gpk_gn_structured_prepare): one memory-bound pass over W1, W2 instead of the triangular solve
+        GPK_PROF_MARK(h, 0);
+        double* coef = S;                                            // 3 nz doubles of scratch (S is free in this mode)
+        GPK_TRY(gpk_i_workspace(h, (size_t)d.rows * lds * sizeof(double), &W));
+        h->work_sig[0] = -1;                                         // (the workspace no longer holds a solve of a known shape)
+        structured_coeff_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, p->p0, p->p1, z, coef, coef + nz, coef + 2 * nz);
+        structured_form_kernel<<<d.rows, 256, 0, h->stream>>>(nz, p->W1, p->W2, p->ldw, p->v0, coef, coef + nz, coef + 2 * nz, W, lds);
+        GPK_LAUNCH_CHECK(h);
+        GPK_PROF_MARK(h, 1);
+    } else {
+        GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
+    }
     double* d_loss = h->d_scalars;
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     // Hb = W^T W and its Cholesky factor, pipelined by column blocks (gpk_factor.hip); d_loss = Hb[nz][nz] before factoring;

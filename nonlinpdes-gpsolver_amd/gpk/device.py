@@ -97,7 +97,7 @@ class DeviceArray:
 class GNProblem:
     """Device-side description of one equation's Gauss-Newton system (gpk_gn_problem)."""
 
-    def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True):
+    def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True, structured=False):
         """dinv: also compute the inverses of the diagonal blocks of the factor(s) once (gpk_trtri_diag; True = blocks of
         dinv_block_for(order) rows, or 256 / 512 / 1024 / 2048), so that the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
         self.ctx = ctx
@@ -130,6 +130,22 @@ class GNProblem:
         ctx._chk(ctx.lib.gpk_gn_dims(C.byref(s), C.byref(nz), C.byref(rows)))
         self.nz, self.rows = nz.value, rows.value
         self._S = self._H = self._delta = self._work = None
+        self.W1 = self.W2 = self.v0 = None
+        if structured:
+            self.prepare_structured()
+
+    def prepare_structured(self):
+        """OPTIONAL (elliptic system): precompute W1 = L^{-1}[I;0;0], W2 = L^{-1}[0;I;0], v0 = L^{-1}F(0) once
+        (gpk_gn_structured_prepare); every later gn_step then forms [L^{-1}A(z) | L^{-1}F(z)] = [W1 diag(d) + W2 | v0 + W1 a + W2 z]
+        in one memory-bound pass instead of the triangular solve.  Not the reference's per-step operation sequence: opt-in."""
+        S, _, _, _ = self.workspace()
+        ld = S.ld
+        self.W1 = DeviceArray(self.ctx, self.rows, self.nz + 1, ld)
+        self.W2 = DeviceArray(self.ctx, self.rows, self.nz + 1, ld)
+        self.v0 = DeviceArray(self.ctx, self.rows)
+        self.ctx._chk(self.ctx.lib.gpk_gn_structured_prepare(self.ctx.h, C.byref(self.struct), S.ptr, S.ld, self.W1.ptr, self.W2.ptr,
+                                                             self.v0.ptr, ld))
+        self.struct.W1, self.struct.W2, self.struct.v0, self.struct.ldw = self.W1.ptr, self.W2.ptr, self.v0.ptr, ld
 
     def workspace(self):
         if self._S is None:
