@@ -145,6 +145,8 @@ typedef struct {
     int dinv_block;                /* block size Dinv / Dinv2 were built with (0 = 256) */
     /* optional (may be NULL), GPK_GN_ELLIPTIC only -- see gpk_gn_structured_prepare */
     const double* W1; const double* W2; const double* v0; int ldw;
+    /* optional (may be NULL), needs W1/W2/v0 -- see gpk_gn_gram_prepare */
+    const double* G; int ldg; const double* pvec;
 } gpk_gn_problem;
 
 /* sizes: nz unknowns, rows of the stacked S = [L^{-1}A | L^{-1}F] buffer */
@@ -166,6 +168,15 @@ int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double
  * forms  S = [W1 diag(d(z)) + W2 | v0 + W1 (alpha z^m) + W2 z]  in one memory-bound pass instead of the triangular solve.  Same
  * iterates up to rounding (tests/test_gpu_structured.py); the product, the factorisation and the update are unchanged. */
 int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* S, int lds, double* W1, double* W2, double* v0, int ldw);
+/* OPTIONAL second level of the structured mode (elliptic system): with the Gram blocks of W = [W1 W2],
+ *   G = [G11; G12; G21; G22]  (four nz x nz blocks stacked, leading dimension ldg >= nz; Gij = Wi^T Wj),
+ *   pvec = [W1^T v0 (nz); W2^T v0 (nz); v0^T v0 (1)],
+ * computed ONCE by this call from W1, W2, v0 (host_prob must carry them), gpk_gn_step assembles the bordered matrix directly,
+ *   H/2 = D G11 D + D G12 + G21 D + G22,   g/2 = D q1 + q2,   loss = v0^T v0 + a.p1 + z.p2 + a.q1 + z.q2
+ *   (D = diag(alpha m z^(m-1)), a = alpha z^m, q1 = G11 a + G12 z + p1, q2 = G21 a + G22 z + p2),
+ * in O(nz^2) memory-bound work per step: neither the triangular solve nor the product S^T S is executed; the Cholesky
+ * factorisation of H, the solve and the update are unchanged.  Same iterates up to rounding (tests/test_gpu_structured.py). */
+int gpk_gn_gram_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* G, int ldg, double* pvec);
 /* building blocks of gpk_gn_step for the column-sharded multi-GPU step: S <- [A(z) | F(z)] (no solve), y += alpha x */
 int gpk_gn_build(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* S, int lds);
 /* Same with unknown j stored in column n_z-1-j (elliptic system only): column c < n_z of [A | F] is then zero above row

@@ -280,12 +280,95 @@ __global__ __launch_bounds__(256) void structured_form_kernel(int nz, const doub
     if (threadIdx.x == 0) s[nz] = v0[r] + ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// w[r] = v0[r] + sum_c (a[c] W1[r][c] + z[c] W2[r][c]) = (L^{-1}F(z))[r]: the Gram level's loss ||w||^2 is taken from w itself -- as
+// the quadratic form v0^T v0 + ... of terms of size 1e16 it keeps three digits near convergence (loss 1e4)
+__global__ __launch_bounds__(256) void structured_w_kernel(int nz, const double* __restrict__ W1, const double* __restrict__ W2, long ldw,
+                                                           const double* __restrict__ v0, const double* __restrict__ acol,
+                                                           const double* __restrict__ zcol, double* __restrict__ w) {
+    __shared__ double red[4];
+    const long r = blockIdx.x;
+    const double* w1 = W1 + r * ldw;
+    const double* w2 = W2 + r * ldw;
+    const int cz = (int)max(0L, (long)nz - 1 - r);                   // W1, W2 are zero left of this column
+    double acc = 0.0;
+    for (int c = cz + (int)threadIdx.x; c < nz; c += 256) acc = fma(acol[c], w1[c], fma(zcol[c], w2[c], acc));
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) w[r] = v0[r] + ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
 __global__ void sub_kernel(long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = a[i] - b[i];
 }
 
-int g_structured = 1;                // gpk_debug_set key 40: 0 = ignore W1/W2/v0 (always the triangular solve)
+// ---- second level: the bordered matrix straight from the Gram blocks of W (optional, gpk_gn_gram_prepare) -----------------------
+// one workgroup per column index c (a row of the four blocks): q1[c] = G11[c,:] a + G12[c,:] z + p1[c], q2[c] = G21[c,:] a + G22[c,:] z + p2[c]
+__global__ __launch_bounds__(256) void gram_gemv_kernel(int nz, const double* __restrict__ G, long ldg, const double* __restrict__ pvec,
+                                                        const double* __restrict__ acol, const double* __restrict__ zcol,
+                                                        double* __restrict__ q) {
+    __shared__ double red[2][4];
+    const long c = blockIdx.x;
+    const double* g11 = G + c * ldg;
+    const double* g12 = G + ((long)nz + c) * ldg;
+    const double* g21 = G + (2L * nz + c) * ldg;
+    const double* g22 = G + (3L * nz + c) * ldg;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < nz; k += 256) {
+        const double a = acol[k], z = zcol[k];
+        s1 = fma(g11[k], a, fma(g12[k], z, s1));
+        s2 = fma(g21[k], a, fma(g22[k], z, s2));
+    }
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        q[c] = pvec[c] + ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        q[nz + c] = pvec[nz + c] + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
+// Hb[c][c'] (c' <= c) = d_c G11 d_c' + d_c G12 + G21 d_c' + G22; border row Hb[nz][c] = d_c q1[c] + q2[c]; one workgroup per row
+__global__ __launch_bounds__(256) void gram_form_kernel(int nz, const double* __restrict__ G, long ldg, const double* __restrict__ dcol,
+                                                        const double* __restrict__ q, double* __restrict__ Hb, long ldh) {
+    const long c = blockIdx.x;
+    if (c == nz) {
+        for (int k = threadIdx.x; k < nz; k += 256) Hb[(long)nz * ldh + k] = fma(dcol[k], q[k], q[nz + k]);
+        return;
+    }
+    const double* g11 = G + c * ldg;
+    const double* g12 = G + ((long)nz + c) * ldg;
+    const double* g21 = G + (2L * nz + c) * ldg;
+    const double* g22 = G + (3L * nz + c) * ldg;
+    const double dc = dcol[c];
+    double* hrow = Hb + c * ldh;
+    for (int k = threadIdx.x; k <= c; k += 256) {
+        const double dk = dcol[k];
+        hrow[k] = fma(dc, fma(g11[k], dk, g12[k]), fma(g21[k], dk, g22[k]));
+    }
+}
+
+// loss = pvec[2nz] + a.p1 + z.p2 + a.q1 + z.q2 -> Hb[nz][nz] and d_loss
+__global__ __launch_bounds__(1024) void gram_loss_kernel(int nz, const double* __restrict__ pvec, const double* __restrict__ acol,
+                                                         const double* __restrict__ zcol, const double* __restrict__ q,
+                                                         double* __restrict__ corner, double* __restrict__ d_loss) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int k = threadIdx.x; k < nz; k += 1024) s += acol[k] * (pvec[k] + q[k]) + zcol[k] * (pvec[nz + k] + q[nz + k]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        t += pvec[2 * nz];
+        *corner = t; *d_loss = t;
+    }
+}
+
+int g_structured = 1;                // gpk_debug_set key 40: 0 = ignore W1/W2/v0 (always the triangular solve); 1 = honour W1/W2/v0 only
+                                     // (never the Gram blocks); 2 would be redundant: the Gram level is used whenever G/pvec are set
 
 }  // namespace
 
@@ -316,6 +399,24 @@ extern "C" int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* p, 
     return rc;
 }
 
+extern "C" int gpk_gn_gram_prepare(gpk_handle h, const gpk_gn_problem* p, double* G, int ldg, double* pvec) {
+    if (!h || !G || !pvec) return GPK_ERR_ARG;
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    if (p->system != GPK_GN_ELLIPTIC || !p->W1 || !p->W2 || !p->v0) return gpk_bad_arg(h, "gram_prepare: elliptic system with W1/W2/v0 only");
+    const int nz = d.nz;
+    if (ldg < nz || p->ldw < nz + 1) return gpk_bad_arg(h, "gram_prepare: ldg/ldw");
+    const double* Wm[2] = {p->W1, p->W2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)                                  // Gij = Wi^T Wj (full blocks: the gemv reads rows of all four)
+            GPK_TRY(gpk_i_gemm(h, true, false, nz, nz, d.rows, 1.0, Wm[i], p->ldw, Wm[j], p->ldw, 0.0, G + (long)(2 * i + j) * nz * ldg, ldg, false));
+    for (int i = 0; i < 2; ++i)                                      // p_i = Wi^T v0 (a one-column product)
+        GPK_TRY(gpk_i_gemm(h, true, false, nz, 1, d.rows, 1.0, Wm[i], p->ldw, p->v0, 1, 0.0, pvec + (long)i * nz, 1, false));
+    GPK_TRY(gpk_i_dot(h, p->v0, p->v0, d.rows, pvec + 2L * nz));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int gpk_gn_dims(const gpk_gn_problem* p, int* nz, int* s_rows) {
     Dims d;
     if (!p || gn_dims(p, d) != 0) return GPK_ERR_ARG;
@@ -341,7 +442,25 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         gpk_handle h; explicit SlopeGuard(gpk_handle hh, int s) : h(hh) { h->lead_div = s; } ~SlopeGuard() { h->lead_div = 1; }
     } slope_guard(h, rev == 3 ? 3 : 1);
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
-    if (g_structured && p->system == GPK_GN_ELLIPTIC && p->W1 && p->W2 && p->v0 && p->ldw >= nz + 1) {
+    const bool gram = g_structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
+    double* d_loss = h->d_scalars;
+    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    if (gram) {
+        // optional Gram level (gpk_gn_gram_prepare): the bordered matrix assembled in O(nz^2), no solve and no product this step
+        GPK_PROF_MARK(h, 0);
+        double* coef = S;                                            // d, a, z (column order), then q1, q2: 5 nz doubles of scratch
+        structured_coeff_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, p->p0, p->p1, z, coef, coef + nz, coef + 2 * nz);
+        gram_gemv_kernel<<<nz, 256, 0, h->stream>>>(nz, p->G, p->ldg, p->pvec, coef + nz, coef + 2 * nz, coef + 3 * nz);
+        GPK_PROF_MARK(h, 1);
+        gram_form_kernel<<<nz + 1, 256, 0, h->stream>>>(nz, p->G, p->ldg, coef, coef + 3 * nz, Hb, ldh);
+        gram_loss_kernel<<<1, 1024, 0, h->stream>>>(nz, p->pvec, coef + nz, coef + 2 * nz, coef + 3 * nz, Hb + (long)nz * ldh + nz, d_loss);
+        // (the reported loss from w = L^{-1}F(z) itself, see structured_w_kernel; w lives behind the five coefficient vectors in S)
+        structured_w_kernel<<<d.rows, 256, 0, h->stream>>>(nz, p->W1, p->W2, p->ldw, p->v0, coef + nz, coef + 2 * nz, coef + 5 * nz);
+        GPK_LAUNCH_CHECK(h);
+        GPK_TRY(gpk_i_dot(h, coef + 5 * nz, coef + 5 * nz, d.rows, d_loss));
+        h->pipe_tev_used = 0; h->prof_pipelined = 0;
+        GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));
+    } else if (g_structured && p->system == GPK_GN_ELLIPTIC && p->W1 && p->W2 && p->v0 && p->ldw >= nz + 1) {
         // optional structured solve (gpk_gn_structured_prepare): one memory-bound pass over W1, W2 instead of the triangular solve
         GPK_PROF_MARK(h, 0);
         double* coef = S;                                            // 3 nz doubles of scratch (S is free in this mode)
@@ -354,11 +473,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     } else {
         GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     }
-    double* d_loss = h->d_scalars;
-    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     // Hb = W^T W and its Cholesky factor, pipelined by column blocks (gpk_factor.hip); d_loss = Hb[nz][nz] before factoring;
     // the last row of the factor is (L_H^{-1} g/2)^T
-    GPK_TRY(gpk_i_syrk_potrf(h, W, lds, d.rows, nz + 1, rev ? nz : 0, Hb, ldh, d_loss));
+    if (!gram) GPK_TRY(gpk_i_syrk_potrf(h, W, lds, d.rows, nz + 1, rev ? nz : 0, Hb, ldh, d_loss));
     GPK_PROF_MARK(h, 2);
     GPK_PROF_MARK(h, 3);
     double* dl = rev ? S : delta;                                    // scratch for the (reversed-order) solution: S is free now

@@ -98,7 +98,8 @@ class GNProblem:
     """Device-side description of one equation's Gauss-Newton system (gpk_gn_problem)."""
 
     def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True, structured=False):
-        """dinv: also compute the inverses of the diagonal blocks of the factor(s) once (gpk_trtri_diag; True = blocks of
+        """structured: False (default: the reference's operation sequence every step), True / 1 (prepare_structured), 2 (+ prepare_gram).
+        dinv: also compute the inverses of the diagonal blocks of the factor(s) once (gpk_trtri_diag; True = blocks of
         dinv_block_for(order) rows, or 256 / 512 / 1024 / 2048), so that the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
         self.ctx = ctx
         self.keep = []
@@ -130,9 +131,11 @@ class GNProblem:
         ctx._chk(ctx.lib.gpk_gn_dims(C.byref(s), C.byref(nz), C.byref(rows)))
         self.nz, self.rows = nz.value, rows.value
         self._S = self._H = self._delta = self._work = None
-        self.W1 = self.W2 = self.v0 = None
+        self.W1 = self.W2 = self.v0 = self.G = self.pvec = None
         if structured:
             self.prepare_structured()
+            if int(structured) == 2:
+                self.prepare_gram()
 
     def prepare_structured(self):
         """OPTIONAL (elliptic system): precompute W1 = L^{-1}[I;0;0], W2 = L^{-1}[0;I;0], v0 = L^{-1}F(0) once
@@ -146,6 +149,15 @@ class GNProblem:
         self.ctx._chk(self.ctx.lib.gpk_gn_structured_prepare(self.ctx.h, C.byref(self.struct), S.ptr, S.ld, self.W1.ptr, self.W2.ptr,
                                                              self.v0.ptr, ld))
         self.struct.W1, self.struct.W2, self.struct.v0, self.struct.ldw = self.W1.ptr, self.W2.ptr, self.v0.ptr, ld
+
+    def prepare_gram(self):
+        """OPTIONAL second level (needs prepare_structured): the Gram blocks G = [W1 W2]^T [W1 W2] and W^T v0 once
+        (gpk_gn_gram_prepare); every later gn_step assembles the bordered matrix in O(nz^2) -- no solve, no product."""
+        ldg = pad_ld(self.nz)
+        self.G = DeviceArray(self.ctx, 4 * self.nz, self.nz, ldg)
+        self.pvec = DeviceArray(self.ctx, 2 * self.nz + 1)
+        self.ctx._chk(self.ctx.lib.gpk_gn_gram_prepare(self.ctx.h, C.byref(self.struct), self.G.ptr, ldg, self.pvec.ptr))
+        self.struct.G, self.struct.ldg, self.struct.pvec = self.G.ptr, ldg, self.pvec.ptr
 
     def workspace(self):
         if self._S is None:

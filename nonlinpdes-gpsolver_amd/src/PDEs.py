@@ -77,9 +77,9 @@ class _GPEquation(object):
             if getattr(self, '_dL', None) is None:
                 raise RuntimeError('call Gram_matrix() and Gram_Cholesky() first')
             p0, p1, lam = self._gn_params()
-            # GPK_STRUCTURED=1 (opt-in, elliptic system only): the z-independent solves are done once and every step forms
+            # GPK_STRUCTURED=1 / 2 (opt-in, elliptic system only; 2 adds the Gram level, gpk_gn_gram_prepare): the z-independent solves are done once and every step forms
             # [L^{-1}A(z) | L^{-1}F(z)] from them (gpk_gn_structured_prepare) -- same iterates, about half the time per step
-            structured = os.environ.get('GPK_STRUCTURED') == '1' and self._system == 'Nonlinear_elliptic'
+            structured = (int(os.environ.get('GPK_STRUCTURED', '0') or 0) if self._system == 'Nonlinear_elliptic' else 0)
             self._prob = gpk.GNProblem(get_context(), self._system, self.N_domain, self.N_boundary, self.rhs_f, self.bdy_g,
                                        self._dL, p0=p0, p1=p1, pen_lambda=lam, structured=structured)
         return self._prob

@@ -20,7 +20,7 @@ def test_structured_step_matches_default_and_oracle(Nd, Nb, nugget):
     assert ctx.potrf(T) == 0
     z0 = rng.normal(size=Nd)
     out = []
-    for structured in (False, True):
+    for structured in (False, True, 2):
         prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0, structured=structured)
         z = ctx.array(z0)
         hist = []
@@ -30,13 +30,15 @@ def test_structured_step_matches_default_and_oracle(Nd, Nb, nugget):
             hist.append(loss)
         hist.append(ctx.gn_loss(prob, z))
         out.append((z.download().ravel().copy(), np.array(hist)))
-    (za, ha), (zb, hb) = out
+    (za, ha), (zb, hb), (zc, hc) = out
     assert np.linalg.norm(zb - za) <= 1e-9 * np.linalg.norm(za)
     np.testing.assert_allclose(hb, ha, rtol=1e-7)
+    assert np.linalg.norm(zc - za) <= 1e-8 * np.linalg.norm(za)          # Gram level: O(nz^2) assembly of the bordered matrix
+    np.testing.assert_allclose(hc, ha, rtol=1e-6)
     if Nd <= 400:
         Theta = O.add_nugget(O.gram_matrix_assembly(Xd, Xb), 'Nonlinear_elliptic', Nd, Nb, nugget)[0]
         sol_ref, hist_ref = O.gn_method(O.EllipticSystem(1.0, 3.0, f, g), [O.cholesky(Theta)], z0, 4, 1)
-        for zz in (za, zb):                                          # both paths within the parity bound of the oracle (4 steps from a random start)
+        for zz in (za, zb, zc):                                          # both paths within the parity bound of the oracle (4 steps from a random start)
             assert np.linalg.norm(zz - sol_ref) <= 1e-6 * np.linalg.norm(sol_ref)
         np.testing.assert_allclose(hb, hist_ref, rtol=1e-6)
     ctx.lib.gpk_debug_set(40, 0)                                     # the switch: W1/W2/v0 present but ignored -> the default path, bit for bit

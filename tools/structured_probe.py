@@ -18,7 +18,7 @@ ctx = gpk.Context(0)
 T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-13, 'adaptive')
 assert ctx.potrf(T) == 0
 res = {}
-for structured in (False, True):
+for structured in (False, True, 2):
     t0 = time.perf_counter()
     prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0, structured=structured)
     ctx.synchronize(); tprep = time.perf_counter() - t0
@@ -29,8 +29,9 @@ for structured in (False, True):
         dt = time.perf_counter() - t0
         its.append((z.download().ravel().copy(), loss, dt))
     res[structured] = its
-    print('structured' if structured else 'default   ', 'setup %.1f ms;' % (tprep * 1e3), 'ms per step (last 6): %.3f;' % (1e3 * np.mean([i[2] for i in its[4:]])),
+    print({False: 'default   ', True: 'structured', 2: 'gram level'}[structured], 'setup %.1f ms;' % (tprep * 1e3), 'ms per step (last 6): %.3f;' % (1e3 * np.mean([i[2] for i in its[4:]])),
           'rms error of the last iterate %.3e' % np.sqrt(np.mean((its[-1][0] - truth) ** 2)))
     prob.release_workspace()
-print('relative difference of the iterates, step by step:', ' '.join('%.1e' % (np.linalg.norm(a[0] - b[0]) / np.linalg.norm(b[0])) for a, b in zip(res[True], res[False])))
-print('relative difference of the in-step losses      :', ' '.join('%.1e' % (abs(a[1] - b[1]) / abs(b[1])) for a, b in zip(res[True], res[False])))
+for mode in (True, 2):
+    print(mode, 'relative difference of the iterates, step by step:', ' '.join('%.1e' % (np.linalg.norm(a[0] - b[0]) / np.linalg.norm(b[0])) for a, b in zip(res[mode], res[False])))
+    print(mode, 'relative difference of the in-step losses      :', ' '.join('%.1e' % (abs(a[1] - b[1]) / abs(b[1])) for a, b in zip(res[mode], res[False])))
