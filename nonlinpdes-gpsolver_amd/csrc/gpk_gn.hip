@@ -445,6 +445,8 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     const bool gram = g_structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
     double* d_loss = h->d_scalars;
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    if ((gram || (g_structured && p->W1)) && (long)d.rows * lds < 5L * nz + d.rows)
+        return gpk_bad_arg(h, "gn: S too small for the scratch vectors of the structured modes");
     if (gram) {
         // optional Gram level (gpk_gn_gram_prepare): the bordered matrix assembled in O(nz^2), no solve and no product this step
         GPK_PROF_MARK(h, 0);
