@@ -139,6 +139,28 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(gpk.declared_symbols()), declared ^ set(gpk.declared_symbols())
 
 
+def test_gn_problem_struct_matches_header():
+    """gpk/_lib.py mirrors `gpk_gn_problem` field by field (name, order, kind): a drift would shift every later field silently"""
+    import gpk._lib as L
+    hdr = open(os.path.join(ROOT, 'include', 'gpk.h')).read()
+    body = re.search(r'typedef struct \{(.*?)\} gpk_gn_problem;', hdr, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        m = re.match(r'(const\s+double\s*\*|int|double)\s*(.*)', decl)
+        assert m, decl
+        kind = {'int': ctypes.c_int, 'double': ctypes.c_double}.get(m.group(1), ctypes.c_void_p)
+        for name in m.group(2).split(','):
+            fields.append((name.strip().lstrip('*').strip(), kind))
+    mirror = [(n, t) for n, t in L.GNProblemStruct._fields_]
+    assert [n for n, _ in fields] == [n for n, _ in mirror]
+    for (n, t), (_, u) in zip(fields, mirror):
+        assert t is u, (n, t, u)
+
+
 def test_no_cpu_fallback_without_device():
     """On a machine without a gfx950 device the product path must fail loudly (never route through the oracle)."""
     import gpk
