@@ -502,7 +502,7 @@ __device__ __forceinline__ int panel_factor_lane_rows(double* __restrict__ Pc, i
     return bad;
 }
 
-template <int PW>
+template <int PW, bool UNROLLED>
 __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, int nb, int below,
                                                                int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
     static_assert(PW == 8 || PW == 16, "panel width");
@@ -623,8 +623,7 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
     const int npan = (nb + PW - 1) / PW;
     // (a ROLLED loop over the panels: the factorisation code of wave 0 exists once; every accumulator index below is static, the
     // panel index only appears in wave-uniform tests)
-#pragma unroll 1
-    for (int p = 0; p < npan; ++p) {
+    auto iter = [&](const int p) __attribute__((always_inline)) {
         double* __restrict__ Pc = Pb[p & 1];                         // panel p (staged; factored between the barriers)
         double* __restrict__ Pq = Pb[(p + 1) & 1];                   // panel p-1 (still needed for the deferred updates), then panel p+1
         if (p > 0) __syncthreads();                                  // panel p staged by every wave
@@ -666,6 +665,20 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
             }
         }
         if (p == 2) PANEL_STAMP(6);
+    };
+    // ROLLED: the code exists once, but the tile that holds panel p+1 is selected at run time, which the compiler implements by moving
+    // whole accumulator sets between registers (dozens of v_accvgpr_mov per panel) -- 42.8 k cycles per 64 columns at 129 VGPRs, three
+    // workgroups per CU.  UNROLLED: every tile index is a constant -- 28.3 k cycles, but 201 VGPRs + 144 AGPRs, ONE workgroup per CU.
+    // The host picks the unrolled instantiation whenever the grid fits the CUs of the stream it is launched on.
+    if (UNROLLED) {
+#pragma unroll
+        for (int p = 0; p < 64 / PW; ++p) {
+            if (p >= npan) break;
+            iter(p);
+        }
+    } else {
+#pragma unroll 1
+        for (int p = 0; p < npan; ++p) iter(p);
     }
     PANEL_STAMP(2);
 
@@ -908,8 +921,9 @@ __global__ __launch_bounds__(320) void potrf_panel_la_kernel(double* __restrict_
             x[2 * i] = u.x; x[2 * i + 1] = u.y;
         }
     }
-#pragma unroll 1
-    for (int p = 0; p < npan; ++p) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p >= npan) break;                                        // (unrolled: every tile index a constant, see potrf_panel_mfma_kernel)
         double* __restrict__ Fc = Fb[p & 1];
         const double* __restrict__ Fp = Fb[(p + 1) & 1];             // factored panel p-1
         double* __restrict__ Qn = Qb[(p + 1) & 1];                   // panel p+1 for the factor wave
@@ -1550,6 +1564,7 @@ int g_mt_trsm = 0;
 int g_persistent_ob = 0;                                             // gpk_debug_set key 7: 1 = persistent outer-block kernel (slower, see its header)
 int g_left_looking_panels = 1;                                       // gpk_debug_set key 18: 0 = right-looking rank-64 updates also in the pipelined chain
 int g_panel_mfma = 1;                                                // gpk_debug_set key 21: 0 = first-design panel kernel (potf2_tile: two columns per barrier)
+int g_panel_unrolled = 1;                                            // gpk_debug_set key 41: 0 = never the unrolled panel kernel; k > 0: taken while the grid is at most k x the CUs of the stream
 int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
@@ -1820,9 +1835,16 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             if (g_panel_mfma == 2)
                 potrf_panel_la_kernel<<<1 + nrb, 320, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                        (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
-            else if (g_panel_mfma)
-                potrf_panel_mfma_kernel<8><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                            (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+            else if (g_panel_mfma) {
+                // one workgroup per CU for the unrolled instantiation: taken when the grid fits the CUs this stream dispatches to
+                const int cus = (h->stream == h->pipe_c && h->pipe_c) ? h->pipe_chain_cus : (h->stream == h->pipe_g && h->pipe_g) ? h->num_cu - h->pipe_chain_cus : h->num_cu;
+                if (g_panel_unrolled && 1 + nrb <= cus * g_panel_unrolled)
+                    potrf_panel_mfma_kernel<8, true><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                                      (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+                else
+                    potrf_panel_mfma_kernel<8, false><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+            }
             else
             potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                 (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
@@ -2141,6 +2163,7 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 extern "C" int gpk_debug_set_mt_trsm(int v) { g_mt_trsm = v; return 0; }
 extern "C" int gpk_debug_set_strip(int v) { g_strip = v; return 0; }
 extern "C" int gpk_debug_set_fused_trsv(int v) { g_fused_trsv = v; return 0; }
+extern "C" int gpk_debug_set_panel_unrolled(int v) { g_panel_unrolled = v; return 0; }
 extern "C" int gpk_debug_set_fused_panel(int v) { g_fused_panel = v; return 0; }
 extern "C" int gpk_debug_set_persistent_ob(int v) { g_persistent_ob = v; return 0; }
 extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; return 0; }

@@ -645,6 +645,7 @@ extern "C" int gpk_debug_set_mt_trsm(int v);
 extern "C" int gpk_debug_set_strip(int v);
 extern "C" int gpk_debug_set_fused_trsv(int v);
 extern "C" int gpk_debug_set_fused_panel(int v);
+extern "C" int gpk_debug_set_panel_unrolled(int v);
 extern "C" int gpk_debug_set_persistent_ob(int v);
 extern "C" int gpk_debug_set_use_dinv(int v);
 extern "C" int gpk_debug_set_eikonal_lz(int v);
@@ -668,6 +669,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 3) return gpk_debug_set_strip(value);
     if (key == 4) return gpk_debug_set_fused_trsv(value);
     if (key == 5) return gpk_debug_set_fused_panel(value);
+    if (key == 41) return gpk_debug_set_panel_unrolled(value);
     if (key == 7) return gpk_debug_set_persistent_ob(value);
     if (key == 8) { g_k64_small = value; return 0; }
     if (key == 9) { g_gemm_extra_lds = value; return 0; }

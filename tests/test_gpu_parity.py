@@ -235,7 +235,7 @@ def test_potrf(ctx, n):
     assert np.linalg.norm(L - Lref) <= 1e-11 * np.linalg.norm(Lref)
 
 
-@pytest.mark.parametrize('panel', [1, 2])
+@pytest.mark.parametrize('panel', [1, 2, 3])
 def test_potrf_grid_larger_than_resident(ctx, panel):
     """Panel kernels with more workgroups than the chip holds at once (the third design keeps one workgroup per CU: 261 > 256): the
     workgroup that stores the diagonal block waits for the others' load tickets, so it must be one that is dispatched AFTER them (a
@@ -249,11 +249,12 @@ def test_potrf_grid_larger_than_resident(ctx, panel):
     A = dA.download()
     A[np.arange(n), np.arange(n)] += n
     dA.upload(A)
-    ctx.lib.gpk_debug_set(21, panel)
+    ctx.lib.gpk_debug_set(21, 1 if panel == 3 else panel)            # 3: second design, unrolled instantiation (one workgroup per CU) for
+    ctx.lib.gpk_debug_set(41, 4 if panel == 3 else 1)                # grids of up to four rounds
     try:
         info = ctx.potrf(dA)
     finally:
-        ctx.lib.gpk_debug_set(21, 1)
+        ctx.lib.gpk_debug_set(21, 1); ctx.lib.gpk_debug_set(41, 1)
     assert info == 0
     L = np.tril(dA.download())
     ii = rng.randint(0, n, 64); jj = rng.randint(0, n, 64)

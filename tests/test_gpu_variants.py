@@ -30,6 +30,8 @@ VARIANTS = [
     ('pipeline with two pre-fork blocks and a 64-CU chain partition', {17: 2, 13: 64}),
     ('leading-zero products walking K downwards', {16: 1}),
     ('first-design Cholesky panel kernel (two columns per barrier)', {21: 0}),
+    ('second-design panel kernel always in its rolled instantiation (three workgroups per CU)', {41: 0}),
+    ('unrolled panel kernel also for grids of up to two rounds', {41: 2}),
     ('third-design Cholesky panel kernel (factor wave one panel ahead; last workgroup stores the diagonal block)', {21: 2}),
     ('Cholesky of Theta on the two-partition pipeline as well', {20: 100000}),
     ('pipelined products without split-K', {24: 0}),
@@ -38,7 +40,7 @@ VARIANTS = [
     ('look-ahead, narrow first block, 256-column blocks', {26: 1, 28: 128, 29: 256}),
     ('192-column blocks, right-looking chain, look-ahead', {26: 1, 28: 64, 29: 192, 18: 0}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500, 35: 192, 36: 256, 38: 6000}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500, 35: 192, 36: 256, 38: 6000, 41: 1}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
