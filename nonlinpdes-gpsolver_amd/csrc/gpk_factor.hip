@@ -503,7 +503,7 @@ __device__ __forceinline__ int panel_factor_lane_rows(double* __restrict__ Pc, i
 }
 
 template <int PW, bool UNROLLED>
-__global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, int nb, int below,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, int nb, int below,
                                                                int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
     static_assert(PW == 8 || PW == 16, "panel width");
     constexpr int PSW = PW + 2;                                      // row stride of a panel buffer: 16-byte aligned rows, conflict-free b64 reads
@@ -667,9 +667,10 @@ __global__ __launch_bounds__(256) void potrf_panel_mfma_kernel(double* __restric
         if (p == 2) PANEL_STAMP(6);
     };
     // ROLLED: the code exists once, but the tile that holds panel p+1 is selected at run time, which the compiler implements by moving
-    // whole accumulator sets between registers (dozens of v_accvgpr_mov per panel) -- 42.8 k cycles per 64 columns at 129 VGPRs, three
-    // workgroups per CU.  UNROLLED: every tile index is a constant -- 28.3 k cycles, but 201 VGPRs + 144 AGPRs, ONE workgroup per CU.
-    // The host picks the unrolled instantiation whenever the grid fits the CUs of the stream it is launched on.
+    // whole accumulator sets between registers (dozens of v_accvgpr_mov per panel).  UNROLLED: every tile index is a constant.  And
+    // left to itself the register allocator spread the unrolled kernel over 201 VGPRs + 144 AGPRs (one workgroup per CU); told to fit
+    // three waves per SIMD (amdgpu_waves_per_eu) it needs 138 VGPRs, no AGPRs, no scratch -- and is faster still.  Cycles per 64 columns
+    // (tools/panel_stamp_probe.py): rolled 42.8 k, rolled with the occupancy hint 33.7 k, unrolled 28.3 k, unrolled with the hint 24.4 k.
     if (UNROLLED) {
 #pragma unroll
         for (int p = 0; p < 64 / PW; ++p) {
@@ -1564,7 +1565,7 @@ int g_mt_trsm = 0;
 int g_persistent_ob = 0;                                             // gpk_debug_set key 7: 1 = persistent outer-block kernel (slower, see its header)
 int g_left_looking_panels = 1;                                       // gpk_debug_set key 18: 0 = right-looking rank-64 updates also in the pipelined chain
 int g_panel_mfma = 1;                                                // gpk_debug_set key 21: 0 = first-design panel kernel (potf2_tile: two columns per barrier)
-int g_panel_unrolled = 1;                                            // gpk_debug_set key 41: 0 = never the unrolled panel kernel; k > 0: taken while the grid is at most k x the CUs of the stream
+int g_panel_unrolled = 1;                                            // gpk_debug_set key 41: 0 = the rolled instantiation of the panel kernel
 int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
@@ -1836,9 +1837,7 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
                 potrf_panel_la_kernel<<<1 + nrb, 320, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                        (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
             else if (g_panel_mfma) {
-                // one workgroup per CU for the unrolled instantiation: taken when the grid fits the CUs this stream dispatches to
-                const int cus = (h->stream == h->pipe_c && h->pipe_c) ? h->pipe_chain_cus : (h->stream == h->pipe_g && h->pipe_g) ? h->num_cu - h->pipe_chain_cus : h->num_cu;
-                if (g_panel_unrolled && 1 + nrb <= cus * g_panel_unrolled)
+                if (g_panel_unrolled)
                     potrf_panel_mfma_kernel<8, true><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
                 else

@@ -249,8 +249,8 @@ def test_potrf_grid_larger_than_resident(ctx, panel):
     A = dA.download()
     A[np.arange(n), np.arange(n)] += n
     dA.upload(A)
-    ctx.lib.gpk_debug_set(21, 1 if panel == 3 else panel)            # 3: second design, unrolled instantiation (one workgroup per CU) for
-    ctx.lib.gpk_debug_set(41, 4 if panel == 3 else 1)                # grids of up to four rounds
+    ctx.lib.gpk_debug_set(21, 1 if panel == 3 else panel)            # 3: second design, rolled instantiation
+    ctx.lib.gpk_debug_set(41, 0 if panel == 3 else 1)
     try:
         info = ctx.potrf(dA)
     finally:

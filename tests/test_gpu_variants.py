@@ -30,8 +30,7 @@ VARIANTS = [
     ('pipeline with two pre-fork blocks and a 64-CU chain partition', {17: 2, 13: 64}),
     ('leading-zero products walking K downwards', {16: 1}),
     ('first-design Cholesky panel kernel (two columns per barrier)', {21: 0}),
-    ('second-design panel kernel always in its rolled instantiation (three workgroups per CU)', {41: 0}),
-    ('unrolled panel kernel also for grids of up to two rounds', {41: 2}),
+    ('second-design panel kernel in its rolled instantiation', {41: 0}),
     ('third-design Cholesky panel kernel (factor wave one panel ahead; last workgroup stores the diagonal block)', {21: 2}),
     ('Cholesky of Theta on the two-partition pipeline as well', {20: 100000}),
     ('pipelined products without split-K', {24: 0}),
