@@ -43,6 +43,8 @@ struct gpk_ctx {
     // cleared by the caller around its launches), the partial-sum workspace and the per-tile arrival counters.  One workspace: only
     // one stream at a time may issue split launches (the GEMM stream of the pipeline does)
     int splitk_req = 0;
+    int tile_req = 0;               // 64 / 128: the NEXT gpk_i_gemm calls use 64 x 64 / 128 x 64 tiles whatever the tile count (the caller gets its
+                                    // parallelism from split-K); 0 = automatic
     double* d_splitk_ws = nullptr;
     size_t splitk_ws_cap = 0;       // bytes
     unsigned* d_splitk_cnt = nullptr;

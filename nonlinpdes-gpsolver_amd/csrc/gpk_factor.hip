@@ -1919,6 +1919,7 @@ int g_pipeline_chain_cus = 32;                                       // gpk_debu
 // the overlap pays while the panel chain (~34 us per 64 columns) is comparable to the GEMM work (~n^3): measured 4.24 -> 3.96 ms
 // at n = 4001 (BASELINE config 2) but 35.9 -> 43.8 ms at n = 10001, break-even near n = 5500.
 int g_pipeline_pre = 1;                                              // gpk_debug_set key 17: blocks of the product computed before the fork
+int g_pipeline_tile = 64;                                           // gpk_debug_set key 34: 64 / 128 = tile height of the pipeline's products (parallelism from split-K alone), 0 = automatic (32 rows below 512 tiles).  Phase time at config 2: automatic 3.18-3.23 ms, 64 rows 3.12-3.14, 128 rows 3.47
 int g_pipeline_lookahead = 0;                                        // gpk_debug_set key 26: 0 = block j's update with block j-1 as ONE product after the chain of j-1
 int g_pipeline_units = 1000;                                          // gpk_debug_set key 24: workgroups aimed at per product launch of the pipeline (split-K; 0 = no split).  Measured at config 2, phase time: 0 / 1000 / 1500 / 2000 / 3000 -> 3.85 / 3.57 / 3.58 / 3.60 / 3.62 ms
 int g_pipeline_max_n = 7000;                                         // gpk_debug_set key 14: pipelined only up to this order (with the split-K products, product + factorisation per step: order 6001 7.18 -> 6.50 ms, 7001 13.7 -> 13.6, 8501 22.3 -> 23.3, 10001 35.8 -> 38.6)
@@ -2012,11 +2013,13 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
     auto product = [&](int jb, int je) {
         const int j0 = bnd[jb], j1 = bnd[je < J ? je : J];
         // few tiles, long K: split K so that the launch has about g_pipeline_units workgroups (see GemmArgs::splitk)
-        const long tiles = (long)gpk_ceil_div(nc - j0, 32) * gpk_ceil_div(j1 - j0, 64);
+        const int th = g_pipeline_tile == 128 ? 128 : g_pipeline_tile == 64 ? 64 : 32;
+        const long tiles = (long)gpk_ceil_div(nc - j0, th) * gpk_ceil_div(j1 - j0, 64);
         h->splitk_req = g_pipeline_units > 0 ? (int)((g_pipeline_units + tiles / 2) / tiles) : 0;
+        h->tile_req = jb > 0 ? g_pipeline_tile : 0;
         const int r = gpk_i_gemm(h, true, false, nc - j0, j1 - j0, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
                                  lead > j0 ? lead - j0 : 0, false, true);
-        h->splitk_req = 0;
+        h->splitk_req = 0; h->tile_req = 0;
         return r;
     };
     hipEvent_t* ev_ready = h->pipe_ev.data();                        // [J]
@@ -2170,6 +2173,7 @@ extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_widths(int key, int v) { (key == 28 ? g_pipeline_w0 : g_pipeline_ob) = v; return 0; }
+extern "C" int gpk_debug_set_pipeline_tile(int v) { g_pipeline_tile = v; return 0; }
 extern "C" int gpk_debug_set_solve_splitk(int v) { g_solve_splitk = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_lookahead(int v) { g_pipeline_lookahead = v; return 0; }
 extern "C" int gpk_debug_set_pipeline_units(int v) { g_pipeline_units = v; return 0; }

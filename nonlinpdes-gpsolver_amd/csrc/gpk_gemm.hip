@@ -657,6 +657,7 @@ extern "C" int gpk_debug_set_pipeline_pre(int v);
 extern "C" int gpk_debug_set_pipeline_units(int v);
 extern "C" int gpk_debug_set_pipeline_lookahead(int v);
 extern "C" int gpk_debug_set_solve_splitk(int v);
+extern "C" int gpk_debug_set_pipeline_tile(int v);
 extern "C" int gpk_debug_set_structured(int v);
 extern "C" int gpk_debug_set_pipeline_widths(int key, int v);
 extern "C" int gpk_debug_set_left_looking_panels(int v);
@@ -685,6 +686,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 24) return gpk_debug_set_pipeline_units(value);
     if (key == 26) return gpk_debug_set_pipeline_lookahead(value);
     if (key == 30) return gpk_debug_set_solve_splitk(value);
+    if (key == 34) return gpk_debug_set_pipeline_tile(value);
     if (key == 40) return gpk_debug_set_structured(value);
     if (key == 28 || key == 29) return gpk_debug_set_pipeline_widths(key, value);
     if (key == 18) return gpk_debug_set_left_looking_panels(value);
@@ -736,7 +738,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     if (g.tri_a) t64 /= 2;                                            // workgroups handle pairs of row tiles
     // (also for long K: restricting this to K <= 1024 was measured slower on the 512-column products of the pipelined SYRK and on
     // the mid-size updates of the triangular solve -- 504 tiles of 64x64 leave the CUs at 2-3 workgroups)
-    if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
+    if (g_force_cfg == 0 && h->tile_req == 128 && !lower_only && !g.tri_a) return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);
+    if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64 && h->tile_req != 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
     // (A "round model" -- co-resident workgroups start and finish together, a partly filled last round costs at least half a round, so
     // e.g. 1260 tiles of 64 rows should lose against 2457 tiles of 32 rows -- was tried as the selector and is wrong for this kernel:
     // 383 -> 420 us for that launch, 1384 -> 1477 us for the 3276-tile one; only launches below 0.6 rounds gained, 121 -> 105 us.)

@@ -34,12 +34,14 @@ VARIANTS = [
     ('third-design Cholesky panel kernel (factor wave one panel ahead; last workgroup stores the diagonal block)', {21: 2}),
     ('Cholesky of Theta on the two-partition pipeline as well', {20: 100000}),
     ('pipelined products without split-K', {24: 0}),
+    ('pipelined products with 32-row tiles / with 128-row tiles', {34: 0}),
+    ('pipelined products with 128-row tiles', {34: 128}),
     ('pipelined products split into many K chunks', {24: 4000}),
     ('block update of the pipeline in three parts (look-ahead over the last panel of the previous block)', {26: 1}),
     ('look-ahead, narrow first block, 256-column blocks', {26: 1, 28: 128, 29: 256}),
     ('192-column blocks, right-looking chain, look-ahead', {26: 1, 28: 64, 29: 192, 18: 0}),
 ]
-DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500, 35: 192, 36: 256, 38: 6000, 41: 1}
+DEFAULTS = {0: 0, 3: 1, 4: 1, 5: 1, 6: 0, 7: 0, 10: 1, 12: 1, 13: 32, 14: 7000, 16: 0, 17: 1, 18: 1, 20: 0, 21: 1, 24: 1000, 26: 0, 28: 512, 29: 512, 33: 1500, 34: 64, 35: 192, 36: 256, 38: 6000, 41: 1}
 
 
 def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
