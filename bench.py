@@ -93,12 +93,15 @@ def syrk_executed_flops(N, nz, tile=64, bk=16):
     return total
 
 
-def trsm_dinv_executed_flops(N, nz, db=1024, num_cu=256, nb=64, bk=16):
+def trsm_dinv_executed_flops(N, nz, db=1024, num_cu=256, nb=64, bk=16, c0=0, c1=None):
     """(flops, launches) executed by the solve phase S = L^{-1}[A | F] of one step (gpk_i_trsm_left_dinv with lead = n_z, nrhs =
     n_z + 1) -- mirrors csrc/gpk_factor.hip / gpk_gemm.hip: recursion split at multiples of the inverted-block size db, active
     column range rounded down to 64, per 64-wide column tile the K loop starts at floor(max(0, lz - (n0 + 64)) / 16) * 16, the
-    triangular leaf products stop at each row tile's last row.  All of it is ONE kernel, gemm_f64_kernel<.., NN>."""
-    nrhs, lead = nz + 1, nz
+    triangular leaf products stop at each row tile's last row.  All of it is ONE kernel, gemm_f64_kernel<.., NN>.
+    c0, c1: the column shard [c0, c1) of the n_z + 1 right-hand sides a rank of the sharded step solves (gpk_trsm_dinv is then called
+    with nrhs = c1 - c0 and lead = n_z - c0); default: all columns."""
+    c1 = nz + 1 if c1 is None else c1
+    nrhs, lead = c1 - c0, max(nz - c0, 0)
     acc = [0.0, 0]
 
     def gemm(m, n, k, lz, tri):
@@ -132,10 +135,10 @@ def trsm_dinv_executed_flops(N, nz, db=1024, num_cu=256, nb=64, bk=16):
         if n1 >= n:
             n1 = db
         rec(n1, row0)
-        c1 = lead - (row0 + n1)
-        c1 = (c1 // nb) * nb if c1 > 0 else 0
-        if c1 < nrhs:
-            gemm(n - n1, nrhs - c1, n1, max(lead - row0 - c1, 0), False)
+        cu = lead - (row0 + n1)
+        cu = (cu // nb) * nb if cu > 0 else 0
+        if cu < nrhs:
+            gemm(n - n1, nrhs - cu, n1, max(lead - row0 - cu, 0), False)
         rec(n - n1, row0 + n1)
 
     rec(N, 0)
@@ -190,7 +193,9 @@ class AbortWatch:
                 self.out['sharded_config'] = {'error': msg}
                 print(json.dumps(self.out), flush=True)
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            # exit code: 0 keeps a launcher (torchrun tears the job down on the first non-zero exit) from discarding the line rank 0
+            # has just printed; GPK_BENCH_STRICT_EXIT=1 makes every rank that abandons the secondary run leave with 3 instead
+            os._exit(3 if os.environ.get('GPK_BENCH_STRICT_EXIT') == '1' else 0)
 
     def _poll(self):
         while not self.done.wait(0.5):
@@ -241,11 +246,15 @@ def syrk_pipelined_flops(N, nz, tile=64, bk=16, ob=512):
 
 
 # ------------------------------------------------------------------------------------------------------ single GPU
-def run_single(args, workload, comm=None):
+def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=None):
     """One independent solve on this rank's GPU.  With `comm` (N > 1 ranks): the timed region is bracketed by barriers and
     the slowest rank's time counts; value is the aggregate over the N replicas."""
     import torch
     import gpk
+    if steps is not None or warmup is not None:
+        args = argparse.Namespace(**vars(args))
+        args.steps = args.steps if steps is None else steps
+        args.warmup = args.warmup if warmup is None else warmup
     Nd, Nb, _, desc = WORKLOADS[workload]
     N, nz = 2 * Nd + Nb, Nd
     world = comm.world if comm is not None else 1
@@ -274,7 +283,10 @@ def run_single(args, workload, comm=None):
         if info == 0 or nugget >= 1e-8:
             break
         nugget *= 10.0                                            # SURVEY 7 hard part 1: report the nugget actually used
-    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=ALPHA, p1=M_EXP)
+    ctx.synchronize(); t0 = time.perf_counter()
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=ALPHA, p1=M_EXP)   # + gpk_trtri_diag of the factor (once per factor)
+    ctx.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
+    dinv_block = prob.struct.dinv_block
     z = ctx.array(z0)
     prob.workspace()
     losses = []
@@ -335,16 +347,21 @@ def run_single(args, workload, comm=None):
                                    f'{world} independent replicas of the workload, one per GPU (no data-path collective); the '
                                    f'sharded north-star configuration is reported under sharded_config'),
                    'kernel': 'Gaussian', 'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive',
-                   'formulation': 'TRSM(n_z+1 rhs) + SYRK + POTRF(H) + TRSV every step, nothing cached across steps; the '
-                                  'structural zeros of A(z) (column j zero above row j) are skipped inside TRSM and SYRK, '
-                                  'f1_tflops is the DENSE F1 flop count / time (an equivalent rate, not executed flops)', 'seed': 0},
+                   'formulation': 'TRSM(n_z+1 rhs) + SYRK + POTRF(H) + TRSV every step.  Nothing that depends on the iterate is cached '
+                                  'across steps; what IS computed once per factor and reused by every step (like the factor L itself) are the '
+                                  f'inverses of the {dinv_block}-row diagonal blocks of L (gpk_trtri_diag, block size gpk.device.dinv_block_for(N); '
+                                  'its cost is one_time_ms.diagonal_block_inverses) -- the solve then runs as GEMMs only -- and the zeroed region '
+                                  'of the solve workspace left of the leading-zero boundary.  The structural zeros of A(z) (column j zero above '
+                                  'row j) are skipped inside TRSM and SYRK; f1_tflops is the DENSE F1 flop count / time (an equivalent rate, '
+                                  'not executed flops)', 'seed': 0},
         'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': args.warmup + args.steps,
                      'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
         'f1_tflops': world * f1_flops(N, nz) * args.steps / elapsed / 1e12,
         'phases_ms_per_step': {'trsm': prof['trsm_ms'] / steps, 'syrk_and_potrf_H': phase_ms,
                                'syrk_launches_sum': syrk_ms, 'trsv_update': prof['trsv_update_ms'] / steps,
                                'pipelined': bool(pipelined), 'chain_partition_cus': prof['chain_cus'] if pipelined else 0},
-        'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms},
+        'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms, 'diagonal_block_inverses': dinv_ms,
+                        'diagonal_block_rows': dinv_block},
         'roofline': ({'bound': 'mfma',
                       'kernel': 'gemm_f64_kernel<.., NN> = the solve phase S = L^{-1}[A | F]: update products of the recursion and '
                                 'triangular products with the inverted diagonal blocks of the factor, all fp64 MFMA',
@@ -376,13 +393,25 @@ def run_single(args, workload, comm=None):
         'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble_kernel<elliptic>', 'achieved': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               'bytes_per_launch': 8.0 * N * N},
+        # the factorisation of Theta (north star: "MFMA fp64 utilisation for the factorisation"): N^3/3 flops are what a Cholesky
+        # executes (nothing structural to skip) over the whole gpk_potrf call -- panel kernels, rank-64 updates and the trailing
+        # GEMM updates together, HIP events on the handle's stream
+        'roofline_cholesky_theta': {'bound': 'mfma', 'kernel': 'gpk_potrf(Theta): potrf_panel_mfma_kernel chain + gemm_k64_kernel + gemm_f64_kernel<NT> trailing updates',
+                                    'achieved': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 'flops': N ** 3 / 3.0, 'ms': chol_ms},
+        'step_executed': {'flops_per_step': (trsm_flops or 0.0) + syrk_flops + (nz + 1) ** 3 / 3.0,
+                          'tflops': ((trsm_flops or 0.0) + syrk_flops + (nz + 1) ** 3 / 3.0) * args.steps / elapsed / 1e12,
+                          'frac_of_peak': ((trsm_flops or 0.0) + syrk_flops + (nz + 1) ** 3 / 3.0) * args.steps / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                          'note': 'flops EXECUTED by one step (solve with structural zeros skipped + lower-tile product + Cholesky of H) / wall time per step'},
     }
     if out['roofline'] is None:                                   # substitution schedule (debug): the SYRK is the measured GEMM then
         out['roofline'] = out['roofline_syrk']
-    if not args.no_structured and world == 1:
+    if not args.no_structured and world == 1 and not secondary:
         out['structured_step'] = structured_step(args, ctx, gpk, prob, T, Nd, Nb, f, g, z0, sol, Xd)
     if not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(T, N, Nd, Nb, f, g, z0)
+        out['cpu_baseline']['gpu_speedup_vs_reference_sequence'] = out['cpu_baseline']['seconds_per_step'] / (elapsed / args.steps)
+        out['cpu_baseline']['gpu_speedup_vs_triangular_best_cpu'] = out['cpu_baseline']['triangular_seconds_per_step'] / (elapsed / args.steps)
     ctx.close()
     return out if rank == 0 else None
 
@@ -424,7 +453,8 @@ def cpu_baseline(T, N, Nd, Nb, f, g, z0):
     """The CPU oracle on this box's host cores, full workload size, ONE Gauss-Newton step:
     B1 = the reference's operation sequence (general LU solves of the triangular L for Hessian, gradient and loss, LU
     solve of H: src/PDEs.py:86,97,118) -- the stand-in for 'reference JAX on CPU', which cannot be installed here;
-    B2 = the triangular formulation the GPU path uses, on the same BLAS."""
+    B2 = the triangular formulation the GPU path uses (TRSM + SYRK + Cholesky of H), timed twice: on numpy/scipy (OpenBLAS)
+    and on torch CPU (MKL, SURVEY 8d "prefer MKL via torch"); the faster one is reported as the triangular figure."""
     from oracle import gp_oracle as O
     L = np.tril(T.download())
     sysm = O.EllipticSystem(ALPHA, M_EXP, f, g)
@@ -435,7 +465,27 @@ def cpu_baseline(T, N, Nd, Nb, f, g, z0):
     t_b1 = time.perf_counter() - t0
     t0 = time.perf_counter()
     O.gn_method(sysm, [L], z0, 1, 1, faithful=False)
-    t_b2 = time.perf_counter() - t0
+    t_b2_np = time.perf_counter() - t0
+    t_b2_mkl, mkl_threads, mkl_err = None, None, None
+    try:
+        import torch
+        mkl_threads = torch.get_num_threads()
+        Lt = torch.from_numpy(L)
+        def mkl_step():
+            A = torch.from_numpy(np.ascontiguousarray(sysm.A(z0)[0])); F = torch.from_numpy(np.ascontiguousarray(sysm.F(z0)[0]))
+            S = torch.linalg.solve_triangular(Lt, torch.cat([A, F[:, None]], dim=1), upper=False)
+            Hb = S.T @ S
+            Lh = torch.linalg.cholesky(Hb[:Nd, :Nd])
+            d = torch.cholesky_solve(Hb[:Nd, Nd:Nd + 1], Lh)
+            z1 = torch.from_numpy(z0) - d[:, 0]
+            w = torch.linalg.solve_triangular(Lt, torch.from_numpy(np.ascontiguousarray(sysm.F(z1.numpy())[0]))[:, None], upper=False)
+            return float((w * w).sum())
+        t0 = time.perf_counter()
+        mkl_step()
+        t_b2_mkl = time.perf_counter() - t0
+    except Exception as e:                                        # noqa: BLE001 -- reported
+        mkl_err = f'{type(e).__name__}: {e}'
+    t_b2 = min(t for t in (t_b2_np, t_b2_mkl) if t is not None)
     try:
         import threadpoolctl
         threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
@@ -445,7 +495,8 @@ def cpu_baseline(T, N, Nd, Nb, f, g, z0):
             'sample': f'1 Gauss-Newton step at the full workload size (N={N}, n_z={Nd}), reference operation sequence '
                       f'(3 general LU solves of L + LU solve of H) with numpy/scipy BLAS; factor L taken from the device',
             'seconds_per_step': t_b1, 'triangular_formulation_value': 1.0 / t_b2, 'triangular_seconds_per_step': t_b2,
-            'host_cpus': os.cpu_count()}
+            'triangular_seconds_per_step_openblas': t_b2_np, 'triangular_seconds_per_step_torch_mkl': t_b2_mkl,
+            'torch_threads': mkl_threads, 'torch_mkl_error': mkl_err, 'host_cpus': os.cpu_count()}
 
 
 # ------------------------------------------------------------------------------------------------------ sharded
@@ -532,6 +583,17 @@ def run_sharded(args, workload, steps=None, warmup=None):
     out = None
     if rank == 0:
         rate = f1_flops(N, nz) * steps / elapsed / 1e12
+        # flops the step EXECUTES, summed over the ranks (never dense F1 flops over the shortened time): every rank's column
+        # shard of the solve (same model as the one-GPU roofline, per shard), the lower-tile product with the structural zeros skipped
+        # (row-block sharded: the same tiles, distributed) and the Cholesky of Hb counted ONCE -- where it is replicated the copies are
+        # waste, not work, and lower the fraction
+        db = gpk.device.dinv_block_for(N)
+        bounds = solver.column_ranges_lz(nz + 1, nz, N)
+        solve_fl = sum(trsm_dinv_executed_flops(N, nz, db, c0=bounds[r], c1=bounds[r + 1])[0] for r in range(world) if bounds[r + 1] > bounds[r])
+        prod_fl = syrk_executed_flops(N, nz)
+        chol_fl = (nz + 1) ** 3 / 3.0
+        executed = solve_fl + prod_fl + chol_fl
+        ex_rate = executed * steps / elapsed / 1e12
         out = {
             'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
             'value': steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
@@ -539,17 +601,22 @@ def run_sharded(args, workload, steps=None, warmup=None):
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
-                       'parallelism': f'Theta: panel-sharded Cholesky (block-cyclic columns, width {args.panel}, RCCL broadcast); step: '
-                                      f'column-sharded TRSM (GEMM-only, inverted {gpk.device.dinv_block_for(N)}-row diagonal blocks of the factor) + all-gather(S) + row-block-sharded SYRK + all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)',
-                       'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step, nothing cached across steps); structural zeros of A(z) '
-                                      'skipped as on one GPU, column shards cut by work; f1_tflops is the dense-equivalent rate'},
+                       'parallelism': solver.describe(world, gpk.device.dinv_block_for(N)),
+                       'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step; only the factor of Theta and the inverses of its diagonal '
+                                      'blocks are reused across steps); structural zeros of A(z) skipped as on one GPU, column shards cut by '
+                                      'work; f1_tflops is the dense-equivalent rate, roofline.achieved the executed one'},
             'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': warmup + steps,
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
             'f1_tflops': rate,
             'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'diagonal_block_inverses': dinv_ms},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step, dense F1 flops over all ranks)',
-                         'achieved': rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
-                         'frac': rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': None},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step: solve + product + Cholesky of Hb), flops EXECUTED summed over the ranks',
+                         'achieved': ex_rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
+                         'frac': ex_rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': None,
+                         'flops_per_step': {'solve': solve_fl, 'product': prod_fl, 'cholesky_H': chol_fl},
+                         'dense_equivalent_tflops': rate},
+            'roofline_cholesky_theta': {'bound': 'mfma', 'kernel': 'sharded Cholesky of Theta (panel kernels + trailing GEMM updates; broadcasts at N > 1)',
+                                        'achieved': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
+                                        'frac': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world), 'ms': chol_ms},
             'cpu_baseline': None,
         }
     del S, S2, Hb, Theta, Dinv
@@ -568,6 +635,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-structured', action='store_true', help='skip the secondary measurement of the optional structured solve')
     ap.add_argument('--no-sharded-config', action='store_true', help='skip the BASELINE config 5 run reported under sharded_config')
+    ap.add_argument('--no-n10k', action='store_true', help='skip the north-star target size (N_domain = 10000 on one GPU) reported under n10k')
     ap.add_argument('--sharded-path', action='store_true', help='use the multi-rank schedule for the primary workload')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -582,31 +650,48 @@ def main():
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group(os.environ.get('GPK_BENCH_BACKEND', 'nccl'))   # (gloo only in the CPU flow test)
     workload = args.workload if args.workload != 'auto' else 'c2'
+    rank = int(os.environ.get('RANK', '0'))
     if args.sharded_path or workload == 'c5':
         out = run_sharded(args, workload)
     else:
         from gpk.sharded import Comm
         out = run_single(args, workload, Comm() if world > 1 else None)
+        if args.workload == 'auto' and world == 1 and not args.no_n10k:
+            # north-star target size (N_domain = 10^4 on ONE GPU, >= 10x vs the CPU reference sequence): a secondary object of the
+            # same line, its own CPU baselines beside it (B1 = reference operation sequence, ~1 min on the host cores; B2 = triangular)
+            try:
+                nk = run_single(args, 'n10k', None, secondary=True, steps=min(args.steps, 4), warmup=1)
+                out['n10k'] = {k: nk[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'l2_error', 'f1_tflops',
+                                                   'phases_ms_per_step', 'one_time_ms', 'roofline', 'roofline_syrk', 'roofline_cholesky_theta',
+                                                   'step_executed', 'cpu_baseline') if k in nk}
+            except Exception as e:                                # noqa: BLE001 -- reported, the primary value survives
+                out['n10k'] = {'error': f'{type(e).__name__}: {e}'}
         if args.workload == 'auto' and not args.no_sharded_config:
-            watch = AbortWatch(int(os.environ.get('RANK', '0')), out, use_store=use_pg)
+            watch = AbortWatch(rank, out, use_store=use_pg)
             try:                                                  # the value above must survive a failure of the secondary run
                 sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
                 if out is not None and sh is not None:
                     out['sharded_config'] = {k: sh[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling',
-                                                                 'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}
+                                                                 'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline',
+                                                                 'roofline_cholesky_theta') if k in sh}
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
                 msg = f'{type(e).__name__}: {e}'
                 if use_pg:
-                    watch.fail(f"rank {os.environ.get('RANK', '0')}: {msg}")      # does not return (peers may be blocked in a collective)
+                    watch.fail(f"rank {rank}: {msg}")             # does not return (peers may be blocked in a collective)
                 if out is not None:
                     out['sharded_config'] = {'error': msg}
             watch.stop()
-    if use_pg:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    # the ONE line goes out before anything that can still block (a peer that died after its last collective would otherwise
+    # leave rank 0 in the final barrier with the result unprinted)
     if out is not None:
         print(json.dumps(out), flush=True)
+    if use_pg:
+        import threading
+        import torch.distributed as dist
+        threading.Thread(target=lambda: (time.sleep(float(os.environ.get('GPK_FINAL_BARRIER_TIMEOUT', '120'))), sys.stdout.flush(), os._exit(0)),
+                         daemon=True).start()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

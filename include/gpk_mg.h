@@ -1,0 +1,94 @@
+/* gpk_mg.h -- multi-GPU entry points of libgpk.so: the panel-sharded Cholesky factorisation and the column-sharded
+ * Gauss-Newton step of the >= 10k-point configuration (BASELINE config 5), ONE PROCESS PER GPU, exchanges over RCCL.
+ *
+ * What it replaces in the reference: the same calls as gpk_potrf / gpk_gn_step (jnp.linalg.cholesky, src/PDEs.py:77; the
+ * Hessian_GN / GN_method step, src/PDEs.py:89-127) -- the reference has no multi-device path at all (README.md:9 concedes
+ * the dense matrices are "costly when you use more than 10k collocation points"); this is SURVEY 8(e) / 8(b) B3 `gpk_mg_*`.
+ *
+ * Process model.  SURVEY B3 sketched a single-process ncclCommInitAll; the build runs one process per GPU (the launch
+ * contract of bench.py and torch.distributed), so every process creates a gpk_handle on its own device and then a
+ * gpk_mg_handle with its rank and the world size.  The collectives are reached through two function pointers that have
+ * EXACTLY the signatures of ncclBroadcast and ncclAllGather:
+ *   - production: gpk_mg_rccl_init() dlopen()s the RCCL library the process already uses (torch's bundled librccl.so, or
+ *     /opt/rocm/lib/librccl.so.1), creates a communicator from a 128-byte ncclUniqueId that rank 0 obtained with
+ *     gpk_mg_rccl_unique_id() and shipped to the other ranks by any means (bench.py: the torch.distributed store), and
+ *     binds ncclBroadcast / ncclAllGather; or gpk_mg_set_comm() with an existing ncclComm_t passed as an opaque pointer;
+ *   - tests on a one-GPU box (several ranks share the device, which RCCL refuses): host-staged stand-ins.
+ *
+ * Schedule.  Cholesky: 1-D block-cyclic block columns of width `panel_width`; the owner factors its
+ * tall panel with the fused panel kernels, packs it into a contiguous buffer, broadcasts it; every rank unpacks it into
+ * its copy of the matrix (all ranks end with the full factor: 9.2 GB of 288 GB at config 5) and updates the block columns
+ * it owns.  With look-ahead (default for world > 1) the owner of panel k+1 applies panel k to that block column and
+ * factors it on a high-priority stream as soon as panel k has arrived, and its broadcast travels on a third stream while
+ * all ranks are still applying panel k to the rest of their columns.  The schedule is a flat list of operations with
+ * explicit event dependencies -- gpk_mg_plan_potrf() returns it, a pure host function that tests interpret on CPU.
+ * Gauss-Newton step: column shards of S = L^{-1}[A | F] cut by work (leading-zero layout), all-gather of S, cyclic block
+ * rows of Hb = S^T S, all-gather, Cholesky of Hb replicated (world <= 2) or panel-sharded with the same plan, replicated
+ * triangular solve + update: every rank holds the same iterate bit for bit.
+ *
+ * Conventions: as gpk.h (return codes, device pointers, row-major double, asynchronous on the handle's stream except where
+ * a host scalar is returned).  <0 return values from the collectives: -(10000 + ncclResult_t), text in gpk_last_error().
+ */
+#ifndef GPK_MG_H
+#define GPK_MG_H
+
+#include "gpk.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpk_mg_ctx* gpk_mg_handle;
+
+/* signatures of ncclBroadcast / ncclAllGather (datatype: ncclDataType_t as int, ncclDouble = 8, ncclInt32 = 2;
+ * comm: ncclComm_t; stream: hipStream_t); return 0 (ncclSuccess) or an ncclResult_t */
+typedef int (*gpk_mg_bcast_fn)(const void* sendbuf, void* recvbuf, size_t count, int datatype, int root, void* comm, void* stream);
+typedef int (*gpk_mg_allgather_fn)(const void* sendbuf, void* recvbuf, size_t sendcount, int datatype, void* comm, void* stream);
+
+/* h: this process' handle (its device, its stream = the stream results are ordered on).  panel_width: multiple of 64, <= 512. */
+int gpk_mg_create(gpk_handle h, int rank, int world, int panel_width, gpk_mg_handle* out);
+int gpk_mg_destroy(gpk_mg_handle mg);                          /* also destroys a communicator created by gpk_mg_rccl_init */
+/* an existing communicator + the two collectives of the RCCL build that created it (or stand-ins) */
+int gpk_mg_set_comm(gpk_mg_handle mg, void* comm, gpk_mg_bcast_fn bcast, gpk_mg_allgather_fn allgather);
+/* librccl_path: NULL = "librccl.so.1" by the loader's search order.  host_id128: 128 bytes. */
+int gpk_mg_rccl_unique_id(const char* librccl_path, void* host_id128);
+int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* host_id128);
+/* key 0: look-ahead (0 off, 1 on; default on for world > 1);  key 1: Cholesky of Hb (0 replicated, 1 panel-sharded;
+ * default sharded for world >= 4);  key 2: alignment of the column shards of the step (default 128) */
+int gpk_mg_set_option(gpk_mg_handle mg, int key, int value);
+
+/* gpk_potrf over all ranks: A (n x n, ld lda) holds the SAME symmetric matrix on every rank on entry and the complete
+ * lower factor on every rank on return.  host_info: LAPACK info, identical on all ranks (one host read at the end). */
+int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info);
+
+/* gpk_gn_step over all ranks (elliptic system; host_prob->L = the replicated factor, host_prob->Dinv/dinv_block = its
+ * inverted diagonal blocks, gpk_trtri_diag).  S, S2: s_rows x lds each; S2 must be ZERO before the first step and is then
+ * reused across steps (the solve never writes left of the leading-zero boundary).  z is updated identically on every rank.
+ * world == 1: the call is gpk_gn_step itself (S2 unused), bit for bit. */
+int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* host_prob, double* z, double step_size, double* S, int lds, double* S2,
+                   double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);
+
+/* ---- the schedule as data (pure host functions: no device, no handle) -------------------------------------------------- */
+/* operation kinds of a plan entry {kind, a, b, stream}; streams: 0 = the handle's stream (trailing updates), 1 = panel
+ * stream (high priority), 2 = communication stream.  Events are numbered 0 .. 3*nblk-1:
+ *   k           panel k is in place in A on this rank (factored here, or received and unpacked)
+ *   nblk + k    the main stream has applied panel k to this rank's next look-ahead column
+ *   2 nblk + k  the transfer buffer of panel k (slot k mod 2) is free again */
+enum { GPK_MG_FACTOR = 0,   /* a = k: factor block column k (rows k*nb .. n) in place                                   */
+       GPK_MG_PACK = 1,     /* a = k: block column k -> transfer buffer k mod 2                                          */
+       GPK_MG_BCAST = 2,    /* a = k, b = root rank: broadcast transfer buffer k mod 2                                   */
+       GPK_MG_UNPACK = 3,   /* a = k: transfer buffer k mod 2 -> block column k                                          */
+       GPK_MG_UPDATE = 4,   /* a = j, b = k: A[j0:, j-block] -= A[j0:, k-block] A[j-block rows, k-block]^T               */
+       GPK_MG_RECORD = 5,   /* a = event                                                                                 */
+       GPK_MG_WAIT = 6 };   /* a = event                                                                                 */
+/* host_ops: cap entries of 4 ints; *host_count = entries needed (call with cap = 0 to size).  Every WAIT refers to an event
+ * RECORDed earlier in the list, so issuing the list in order is a valid host order for any stream mapping. */
+int gpk_mg_plan_potrf(int n, int nb, int world, int rank, int lookahead, int* host_ops, int cap, int* host_count);
+/* work-balanced contiguous column shards of the leading-zero right-hand side (column c < lead starts at row lead-1-c, its
+ * solve costs ~(rows - start)^2): host_bounds[world + 1], multiples of `align` except the last */
+int gpk_mg_column_bounds(int ncols, int lead, int rows, int world, int align, int* host_bounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPK_MG_H */

@@ -108,5 +108,9 @@ int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X
 int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x);   // x contiguous
 int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_out);    // d_out device scalar
 int gpk_i_ensure_points(gpk_handle h, size_t doubles);
+// pieces of the Gauss-Newton step used by the multi-GPU schedule (gpk_gn.hip)
+int gpk_i_gn_dims(gpk_handle h, const gpk_gn_problem* p, int* nz, int* rows);
+int gpk_i_gn_finish(gpk_handle h, const gpk_gn_problem* p, int nz, int rev, const double* Hb, int ldh, double* scratch, double* delta,
+                    double* z, double step_size);
 
 static inline int gpk_ceil_div(int a, int b) { return (a + b - 1) / b; }

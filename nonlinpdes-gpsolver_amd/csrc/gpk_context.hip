@@ -216,15 +216,21 @@ int gpk_i_ensure_points(gpk_handle h, size_t doubles) {
     return 0;
 }
 
+// Reserved on first use (the first pipelined or forced split-K launch of a handle), each buffer on its own: a handle that never
+// splits a product holds neither, and a failed second allocation does not orphan the first.
 int gpk_i_splitk_reserve(gpk_handle h) {
-    if (h->d_splitk_ws) return 0;
     constexpr size_t WS = (size_t)64 << 20;
     constexpr int NCNT = 65536;
-    GPK_HIP(h, hipMalloc(&h->d_splitk_cnt, NCNT * sizeof(unsigned)));
-    GPK_HIP(h, hipMemset(h->d_splitk_cnt, 0, NCNT * sizeof(unsigned)));
-    h->splitk_cnt_cap = NCNT;
-    GPK_HIP(h, hipMalloc(&h->d_splitk_ws, WS));
-    h->splitk_ws_cap = WS;
+    if (!h->d_splitk_cnt) {
+        GPK_HIP(h, hipMalloc(&h->d_splitk_cnt, NCNT * sizeof(unsigned)));
+        hipError_t e = hipMemset(h->d_splitk_cnt, 0, NCNT * sizeof(unsigned));
+        if (e != hipSuccess) { (void)hipFree(h->d_splitk_cnt); h->d_splitk_cnt = nullptr; return gpk_fail(h, e, "hipMemset", __FILE__, __LINE__); }
+        h->splitk_cnt_cap = NCNT;
+    }
+    if (!h->d_splitk_ws) {
+        GPK_HIP(h, hipMalloc(&h->d_splitk_ws, WS));
+        h->splitk_ws_cap = WS;
+    }
     return 0;
 }
 

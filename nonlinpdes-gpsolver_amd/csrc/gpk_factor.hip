@@ -1927,7 +1927,7 @@ int g_pipeline_max_n = 7000;                                         // gpk_debu
 // Block columns of the pipelined factorisation: a first block of g_pipeline_w0 columns (the chain can only start once its product is
 // there), then blocks of g_pipeline_ob columns; widths are multiples of the panel width, at most 512.
 int g_pipeline_w0 = 512, g_pipeline_ob = 512;                        // gpk_debug_set keys 28 / 29
-static int pipe_setup(gpk_handle h, size_t nev, size_t ntev);
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve = true);
 static std::vector<int> pipe_blocks(int nc) {
     auto norm = [](int w) { w = (w / NB) * NB; return w < NB ? NB : (w > 512 ? 512 : w); };
     std::vector<int> b{0};
@@ -1943,9 +1943,9 @@ static std::vector<int> pipe_blocks(int nc) {
 // the panels' early updates).  HIP multiplexes streams onto a few hardware queues, and streams that land on the same queue
 // serialise; streams created before the context (torch's pool) or after the masked pair did no harm.  GPU_MAX_HW_QUEUES = 8 changed
 // nothing.
-int gpk_i_pipe_streams(gpk_handle h) { return pipe_setup(h, 0, 0); }
+int gpk_i_pipe_streams(gpk_handle h) { return pipe_setup(h, 0, 0, false); }
 
-static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve) {
     // multiples of 32: bits 8k .. 8k+7 of the mask are one CU of shader engine k mod 4 on each of the 8 XCDs, so 32 bits take one CU from
     // every shader engine; other sizes leave the engines uneven (measured: 48 behaves like 32, 80 like 64)
     int c = ((g_pipeline_chain_cus + 16) / 32) * 32;
@@ -1960,7 +1960,7 @@ static int pipe_setup(gpk_handle h, size_t nev, size_t ntev) {
         GPK_HIP(h, hipExtStreamCreateWithCUMask(&h->pipe_g, 8, mg));
         h->pipe_chain_cus = c;
     }
-    GPK_TRY(gpk_i_splitk_reserve(h));                               // split-K products of the GEMM stream (gpk_gemm.hip)
+    if (reserve) GPK_TRY(gpk_i_splitk_reserve(h));                  // split-K products of the GEMM stream (gpk_gemm.hip); not at gpk_create
     while (h->pipe_ev.size() < nev) {
         hipEvent_t e;
         GPK_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2028,7 +2028,11 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
     hipEvent_t* ev_ready2 = h->pipe_ev.data() + 2 * J + 1;           // [J] (lookahead only)
     hipEvent_t* ev_pre = h->pipe_ev.data() + 3 * J + 1;              // [J] (lookahead only)
     int rc = 0, ntev = 0;
-    auto fail = [&](hipError_t e, const char* what) { h->stream = main_s; return gpk_fail(h, e, what, __FILE__, __LINE__); };
+    auto fail = [&](hipError_t e, const char* what) {               // restore the handle's stream and drain both side streams before reporting
+        h->stream = main_s;
+        (void)hipStreamSynchronize(G); (void)hipStreamSynchronize(C);
+        return gpk_fail(h, e, what, __FILE__, __LINE__);
+    };
 #define PIPE_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
     auto timed_product = [&](hipStream_t s, int jb, int je) -> int {  // (HIP events around the launch: bench.py's roofline leg)
         if (h->prof) { hipError_t e = hipEventRecord(h->pipe_tev[ntev], s); if (e != hipSuccess) return fail(e, "hipEventRecord"); }

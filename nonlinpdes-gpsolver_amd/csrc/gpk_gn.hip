@@ -207,12 +207,18 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
         GPK_TRY(gpk_i_workspace(h, (size_t)d.rows * lds * sizeof(double), &W));
         // the solve never writes W left of the leading-zero boundary (rev) -- zero it unless the previous solve into W had
         // exactly this shape, in which case those zeros are still there
-        const long sig[5] = {d.rows, lds, nc, rev ? d.nz : 0, p->system + 1};
+        // (the signature carries the inverted-block size -- the never-written region depends on it -- and is dropped again if the
+        // solve below fails to be issued, so that a later step never trusts zeros this one did not leave behind)
+        const long sig[5] = {d.rows, lds, nc, rev ? d.nz : 0, (long)(p->system + 1) * 4096 + db};
         if (memcmp(sig, h->work_sig, sizeof sig) != 0) {
+            h->work_sig[0] = -1;
             GPK_HIP(h, hipMemsetAsync(W, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
             memcpy(h->work_sig, sig, sizeof sig);
         }
     }
+    struct SigGuard {                                                // any early return below invalidates the cached zero region
+        gpk_handle h; bool armed; ~SigGuard() { if (armed) h->work_sig[0] = -1; }
+    } sig_guard{h, dinv};
     GPK_PROF_MARK(h, 0);
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
     GPK_TRY(build(h, p, z, S, lds, d.nz, 1, rev, family));
@@ -232,6 +238,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
         }
     }
     GPK_PROF_MARK(h, 1);
+    sig_guard.armed = false;                                         // the solve was issued completely
     if (Wout) { *Wout = W; return 0; }                               // gn_step: product and factorisation are pipelined by the caller
     GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, d.rows, alpha, W, lds, W, lds, 0.0, Hb, ldh, true, rev ? d.nz : 0));
     GPK_PROF_MARK(h, 2);
@@ -575,6 +582,32 @@ extern "C" int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* p, const d
     if (gn_dims(&q, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
     GPK_HIP(h, hipMemsetAsync(out, 0, (size_t)d.rows * sizeof(double), h->stream));
     return build(h, &q, z, out, 1, 0, 0);
+}
+
+// ---- building blocks of the multi-GPU step (gpk_mg.hip) ---------------------------------------------------------------------
+// n_z and the row count of the elliptic system handled by the sharded step
+int gpk_i_gn_dims(gpk_handle h, const gpk_gn_problem* p, int* nz, int* rows) {
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    *nz = d.nz; *rows = d.rows;
+    return 0;
+}
+
+// The tail of a step once the bordered matrix Hb is factored (its last row = (L_H^{-1} g/2)^T): backward solve, back to the natural
+// order of the unknowns (rev: the staircase order of gpk_gn_step), update of z.  scratch: nz doubles (rev only).
+int gpk_i_gn_finish(gpk_handle h, const gpk_gn_problem* p, int nz, int rev, const double* Hb, int ldh, double* scratch, double* delta,
+                    double* z, double step_size) {
+    double* dl = rev ? scratch : delta;
+    GPK_HIP(h, hipMemcpyAsync(dl, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, dl));
+    if (rev) {
+        reverse_copy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, dl, delta, rev, p->Nd);
+        axpy_rev_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, dl, z, rev, p->Nd);
+    } else {
+        axpy_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, -step_size, delta, z);
+    }
+    GPK_LAUNCH_CHECK(h);
+    return 0;
 }
 
 extern "C" int gpk_debug_set_use_dinv(int v) { g_use_dinv = v; return 0; }

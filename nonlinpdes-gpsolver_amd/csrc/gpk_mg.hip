@@ -1,0 +1,480 @@
+// gpk_mg.hip -- multi-GPU (one process per GPU) schedule of the factor/solve path behind the C ABI (include/gpk_mg.h).
+//
+// Replaces, for the >= 10k-point configuration, the same reference work as gpk_potrf / gpk_gn_step: jnp.linalg.cholesky of
+// the nugget-regularised Gram matrix (reference src/PDEs.py:75-80) and the Hessian_GN / GN_method step (src/PDEs.py:89-127),
+// which the reference can only run on one device (README.md:9).
+//
+// Everything numerical is the single-GPU building blocks of this library (gpk_i_potrf_panel, gpk_i_gemm,
+// gpk_i_trsm_left_dinv, ...); this file holds (1) the SCHEDULE of the panel-sharded Cholesky as a plan -- a flat list of
+// operations on three streams with explicit event dependencies, produced by a pure host function so that CPU tests can
+// interpret it -- (2) its executor on HIP streams / events with the collectives reached through ncclBroadcast /
+// ncclAllGather-shaped function pointers, (3) the column-sharded Gauss-Newton step, (4) the dlopen() binding of RCCL.
+#include "gpk_common.h"
+#include "../../include/gpk_mg.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+
+struct gpk_mg_ctx {
+    gpk_handle h = nullptr;
+    int rank = 0, world = 1, nb = 512;
+    int lookahead = 0, shard_hb = 0, col_align = 128;
+    void* comm = nullptr;
+    gpk_mg_bcast_fn bcast = nullptr;
+    gpk_mg_allgather_fn allgather = nullptr;
+    bool own_comm = false;
+    void* lib = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    const char* (*errstr)(int) = nullptr;
+    hipStream_t s_panel = nullptr, s_comm = nullptr;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t ev_begin = nullptr;
+    double* buf[2] = {nullptr, nullptr};   // transfer buffers of the panel broadcasts (contiguous (n - k0) x kb images)
+    size_t buf_cap = 0;                    // bytes each
+    double* gsend = nullptr; double* grecv = nullptr;   // persistent all-gather staging of the step
+    size_t gsend_cap = 0, grecv_cap = 0;
+    int* d_infos = nullptr;                // world + 1 ints: [0, world) gathered, [world] mine
+    std::vector<int> bounds;
+};
+
+namespace {
+
+constexpr int NCCL_INT32 = 2, NCCL_DOUBLE = 8;
+
+struct Op { int kind, a, b, stream; };
+
+void make_plan(int n, int nb, int P, int r, int lookahead, std::vector<Op>& ops) {
+    ops.clear();
+    if (n <= 0) return;
+    const int nblk = gpk_ceil_div(n, nb);
+    auto own = [&](int k) { return k % P == r; };
+    auto EA = [&](int k) { return k; };                 // panel k in place on this rank
+    auto EC = [&](int k) { return nblk + k; };          // main stream applied panel k to my next look-ahead column
+    auto EB = [&](int k) { return 2 * nblk + k; };      // transfer buffer of panel k free again
+    if (!lookahead) {
+        // one stream, no events: factor -> (pack, broadcast, unpack) -> update my columns, panel after panel
+        for (int k = 0; k < nblk; ++k) {
+            if (own(k)) { ops.push_back({GPK_MG_FACTOR, k, 0, 0}); if (P > 1) ops.push_back({GPK_MG_PACK, k, 0, 0}); }
+            if (P > 1) {
+                ops.push_back({GPK_MG_BCAST, k, k % P, 0});
+                if (!own(k)) ops.push_back({GPK_MG_UNPACK, k, 0, 0});
+            }
+            for (int j = k + 1; j < nblk; ++j) if (own(j)) ops.push_back({GPK_MG_UPDATE, j, k, 0});
+        }
+        return;
+    }
+    constexpr int M = 0, PN = 1, C = 2;
+    if (own(0)) {
+        ops.push_back({GPK_MG_FACTOR, 0, 0, PN});
+        if (P > 1) ops.push_back({GPK_MG_PACK, 0, 0, PN});
+        ops.push_back({GPK_MG_RECORD, EA(0), 0, PN});
+    }
+    for (int k = 0; k < nblk; ++k) {
+        // ---- panel k travels (communication stream)
+        if (P > 1) {
+            if (own(k)) {
+                ops.push_back({GPK_MG_WAIT, EA(k), 0, C});
+                ops.push_back({GPK_MG_BCAST, k, k % P, C});
+            } else {
+                ops.push_back({GPK_MG_BCAST, k, k % P, C});
+                ops.push_back({GPK_MG_UNPACK, k, 0, C});
+                ops.push_back({GPK_MG_RECORD, EA(k), 0, C});
+            }
+            ops.push_back({GPK_MG_RECORD, EB(k), 0, C});
+        }
+        // ---- look-ahead (panel stream): the owner of panel k+1 applies panel k to that block column FIRST and factors it,
+        //      so that its broadcast overlaps with everybody's remaining updates by panel k
+        if (k + 1 < nblk && own(k + 1)) {
+            ops.push_back({GPK_MG_WAIT, EA(k), 0, PN});
+            if (k >= 1) ops.push_back({GPK_MG_WAIT, EC(k - 1), 0, PN});   // column k+1 has received panels 0 .. k-1 on the main stream
+            ops.push_back({GPK_MG_UPDATE, k + 1, k, PN});
+            ops.push_back({GPK_MG_FACTOR, k + 1, 0, PN});
+            if (P > 1) {
+                if (k >= 1) ops.push_back({GPK_MG_WAIT, EB(k - 1), 0, PN});   // slot (k+1) mod 2 last carried panel k-1
+                ops.push_back({GPK_MG_PACK, k + 1, 0, PN});
+            }
+            ops.push_back({GPK_MG_RECORD, EA(k + 1), 0, PN});
+        }
+        // ---- trailing updates of my other columns (main stream), nearest column first: it is my next look-ahead column
+        bool first = true;
+        for (int j = k + 2; j < nblk; ++j) {
+            if (!own(j)) continue;
+            if (first) ops.push_back({GPK_MG_WAIT, EA(k), 0, M});
+            ops.push_back({GPK_MG_UPDATE, j, k, M});
+            if (first) ops.push_back({GPK_MG_RECORD, EC(k), 0, M});
+            first = false;
+        }
+    }
+    // join: the caller's stream continues only when the last panel is in place and the communication stream has drained
+    ops.push_back({GPK_MG_WAIT, EA(nblk - 1), 0, M});
+    if (P > 1) ops.push_back({GPK_MG_WAIT, EB(nblk - 1), 0, M});
+}
+
+void column_bounds(int ncols, int lead, int rows, int P, int align, std::vector<int>& b) {
+    // mirrors gpk/sharded.py::column_ranges_lz (numpy cumsum + searchsorted(side='left')); all values are integers < 2^53
+    b.assign(1, 0);
+    if (align < 1) align = 1;
+    std::vector<double> w((size_t)std::max(ncols, 0));
+    double acc = 0.0;
+    for (int c = 0; c < ncols; ++c) {
+        const double len = (double)rows - (double)std::max(0, lead - 1 - c);
+        acc += len * len;
+        w[c] = acc;
+    }
+    for (int r = 1; r < P; ++r) {
+        int cut = 0;
+        if (ncols > 0) {
+            const double target = w[ncols - 1] * r / P;
+            cut = (int)(std::lower_bound(w.begin(), w.end(), target) - w.begin());
+        }
+        cut = gpk_ceil_div(cut, align) * align;
+        cut = std::min(std::max(cut, b.back()), ncols);
+        b.push_back(cut);
+    }
+    b.push_back(ncols);
+}
+
+int nccl_fail(gpk_mg_handle mg, int r, const char* what) {
+    char msg[256];
+    snprintf(msg, sizeof msg, "%s failed: %s (ncclResult %d)", what, (mg && mg->errstr) ? mg->errstr(r) : "collective stand-in", r);
+    if (mg && mg->h) mg->h->err = msg;
+    return -(10000 + r);
+}
+
+#define MG_NCCL(mg, call, what) do { int r__ = (call); if (r__ != 0) return nccl_fail((mg), r__, (what)); } while (0)
+
+int ensure_buffers(gpk_mg_handle mg, size_t panel_bytes) {
+    gpk_handle h = mg->h;
+    if (mg->buf_cap >= panel_bytes) return 0;
+    GPK_HIP(h, hipDeviceSynchronize());
+    for (int i = 0; i < 2; ++i) { if (mg->buf[i]) GPK_HIP(h, hipFree(mg->buf[i])); mg->buf[i] = nullptr; }
+    mg->buf_cap = 0;
+    for (int i = 0; i < 2; ++i) GPK_HIP(h, hipMalloc((void**)&mg->buf[i], panel_bytes));
+    mg->buf_cap = panel_bytes;
+    return 0;
+}
+
+int ensure_gather(gpk_mg_handle mg, size_t send_bytes, size_t recv_bytes) {
+    gpk_handle h = mg->h;
+    if (mg->gsend_cap < send_bytes) {
+        GPK_HIP(h, hipDeviceSynchronize());
+        if (mg->gsend) GPK_HIP(h, hipFree(mg->gsend));
+        mg->gsend = nullptr; mg->gsend_cap = 0;
+        GPK_HIP(h, hipMalloc((void**)&mg->gsend, send_bytes));
+        mg->gsend_cap = send_bytes;
+    }
+    if (mg->grecv_cap < recv_bytes) {
+        GPK_HIP(h, hipDeviceSynchronize());
+        if (mg->grecv) GPK_HIP(h, hipFree(mg->grecv));
+        mg->grecv = nullptr; mg->grecv_cap = 0;
+        GPK_HIP(h, hipMalloc((void**)&mg->grecv, recv_bytes));
+        mg->grecv_cap = recv_bytes;
+    }
+    return 0;
+}
+
+int ensure_streams(gpk_mg_handle mg, size_t nev) {
+    gpk_handle h = mg->h;
+    if (!mg->s_panel) {
+        int lo = 0, hi = 0;
+        GPK_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));      // (numerically lower = higher priority)
+        GPK_HIP(h, hipStreamCreateWithPriority(&mg->s_panel, hipStreamNonBlocking, hi));
+        GPK_HIP(h, hipStreamCreateWithPriority(&mg->s_comm, hipStreamNonBlocking, hi));
+        GPK_HIP(h, hipEventCreateWithFlags(&mg->ev_begin, hipEventDisableTiming));
+    }
+    while (mg->ev.size() < nev) {
+        hipEvent_t e;
+        GPK_HIP(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        mg->ev.push_back(e);
+    }
+    return 0;
+}
+
+// The plan, executed: block operations through the handle (its stream switched per operation), collectives through the
+// bound function pointers.  Nothing here synchronises with the host.  pivot indices are reported relative to A.
+int exec_potrf(gpk_mg_handle mg, double* A, int n, int lda) {
+    gpk_handle h = mg->h;
+    const int nb = mg->nb, P = mg->world;
+    if (n <= 0) return 0;
+    const int nblk = gpk_ceil_div(n, nb);
+    const int la = (mg->lookahead && nblk > 1) ? 1 : 0;
+    std::vector<Op> plan;
+    make_plan(n, nb, P, mg->rank, la, plan);
+    if (P > 1) {
+        if (!mg->bcast) return gpk_bad_arg(h, "gpk_mg: world > 1 needs a communicator (gpk_mg_rccl_init / gpk_mg_set_comm)");
+        GPK_TRY(ensure_buffers(mg, (size_t)n * (size_t)std::min(nb, n) * sizeof(double)));
+    }
+    const hipStream_t main_s = h->stream;
+    hipStream_t streams[3] = {main_s, main_s, main_s};
+    if (la) {
+        GPK_TRY(ensure_streams(mg, 3 * (size_t)nblk));
+        streams[1] = mg->s_panel; streams[2] = mg->s_comm;
+        GPK_HIP(h, hipEventRecord(mg->ev_begin, main_s));           // the matrix was produced on the caller's stream
+        GPK_HIP(h, hipStreamWaitEvent(mg->s_panel, mg->ev_begin, 0));
+        GPK_HIP(h, hipStreamWaitEvent(mg->s_comm, mg->ev_begin, 0));
+    }
+    int rc = 0;
+    for (const Op& op : plan) {
+        const hipStream_t s = streams[op.stream];
+        h->stream = s;
+        const int k = (op.kind == GPK_MG_UPDATE) ? op.b : op.a;
+        const int k0 = k * nb, kb = std::min(nb, n - k0);
+        hipError_t e = hipSuccess;
+        switch (op.kind) {
+        case GPK_MG_FACTOR:
+            rc = gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, kb, lda, k0);
+            break;
+        case GPK_MG_PACK:
+            e = hipMemcpy2DAsync(mg->buf[k & 1], (size_t)kb * 8, A + (long)k0 * lda + k0, (size_t)lda * 8, (size_t)kb * 8, (size_t)(n - k0),
+                                 hipMemcpyDeviceToDevice, s);
+            break;
+        case GPK_MG_UNPACK:
+            e = hipMemcpy2DAsync(A + (long)k0 * lda + k0, (size_t)lda * 8, mg->buf[k & 1], (size_t)kb * 8, (size_t)kb * 8, (size_t)(n - k0),
+                                 hipMemcpyDeviceToDevice, s);
+            break;
+        case GPK_MG_BCAST: {
+            const int r = mg->bcast(mg->buf[k & 1], mg->buf[k & 1], (size_t)(n - k0) * kb, NCCL_DOUBLE, op.b, mg->comm, (void*)s);
+            if (r != 0) rc = nccl_fail(mg, r, "panel broadcast");
+            break;
+        }
+        case GPK_MG_UPDATE: {
+            const int j0 = op.a * nb, jb = std::min(nb, n - j0);
+            const double* Lj = A + (long)j0 * lda + k0;              // rows j0.. of panel k
+            rc = gpk_i_gemm(h, false, true, n - j0, jb, kb, -1.0, Lj, lda, Lj, lda, 1.0, A + (long)j0 * lda + j0, lda, false, 0, false, true);
+            break;
+        }
+        case GPK_MG_RECORD: e = hipEventRecord(mg->ev[op.a], s); break;
+        case GPK_MG_WAIT:   e = hipStreamWaitEvent(s, mg->ev[op.a], 0); break;
+        default: rc = gpk_bad_arg(h, "gpk_mg: corrupt plan");
+        }
+        if (e != hipSuccess) rc = gpk_fail(h, e, "gpk_mg plan operation", __FILE__, __LINE__);
+        if (rc) break;
+    }
+    h->stream = main_s;
+    if (rc && la) { (void)hipStreamSynchronize(mg->s_panel); (void)hipStreamSynchronize(mg->s_comm); }
+    return rc;
+}
+
+// LAPACK info over all ranks after a sharded factorisation: every rank saw only the panels it factored.  One all-gather of
+// one int; the smallest positive index wins (negative = a device-side wait expired somewhere).
+int gather_info(gpk_mg_handle mg, int* host_info) {
+    gpk_handle h = mg->h;
+    const int P = mg->world;
+    if (P == 1) {
+        GPK_HIP(h, hipMemcpyAsync(host_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        GPK_HIP(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    GPK_HIP(h, hipMemcpyAsync(mg->d_infos + P, h->d_info, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    MG_NCCL(mg, mg->allgather(mg->d_infos + P, mg->d_infos, 1, NCCL_INT32, mg->comm, (void*)h->stream), "all-gather of info");
+    std::vector<int> all((size_t)P);
+    GPK_HIP(h, hipMemcpyAsync(all.data(), mg->d_infos, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    int info = 0;
+    for (int v : all) {
+        if (v < 0) { info = v; break; }
+        if (v > 0 && (info == 0 || v < info)) info = v;
+    }
+    *host_info = info;
+    return 0;
+}
+
+struct nccl_unique_id { char internal[128]; };
+
+void* open_rccl(const char* path) {
+    void* lib = dlopen(path && path[0] ? path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib && !(path && path[0])) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return lib;
+}
+
+}  // namespace
+
+extern "C" int gpk_mg_plan_potrf(int n, int nb, int world, int rank, int lookahead, int* host_ops, int cap, int* host_count) {
+    if (n < 0 || nb <= 0 || world <= 0 || rank < 0 || rank >= world || !host_count) return GPK_ERR_ARG;
+    std::vector<Op> ops;
+    make_plan(n, nb, world, rank, (lookahead && gpk_ceil_div(n, nb) > 1) ? 1 : 0, ops);
+    *host_count = (int)ops.size();
+    if (host_ops) {
+        const int m = std::min(cap, (int)ops.size());
+        for (int i = 0; i < m; ++i) { host_ops[4 * i] = ops[i].kind; host_ops[4 * i + 1] = ops[i].a; host_ops[4 * i + 2] = ops[i].b; host_ops[4 * i + 3] = ops[i].stream; }
+    }
+    return 0;
+}
+
+extern "C" int gpk_mg_column_bounds(int ncols, int lead, int rows, int world, int align, int* host_bounds) {
+    if (ncols < 0 || world <= 0 || !host_bounds) return GPK_ERR_ARG;
+    std::vector<int> b;
+    column_bounds(ncols, lead, rows, world, align, b);
+    for (int i = 0; i <= world; ++i) host_bounds[i] = b[i];
+    return 0;
+}
+
+extern "C" int gpk_mg_create(gpk_handle h, int rank, int world, int panel_width, gpk_mg_handle* out) {
+    if (!h || !out || world <= 0 || rank < 0 || rank >= world) return GPK_ERR_ARG;
+    if (panel_width <= 0 || panel_width > 512 || panel_width % 64 != 0) return gpk_bad_arg(h, "gpk_mg_create: panel width must be a multiple of 64, at most 512");
+    gpk_mg_ctx* mg = new gpk_mg_ctx();
+    mg->h = h; mg->rank = rank; mg->world = world; mg->nb = panel_width;
+    mg->lookahead = world > 1 ? 1 : 0;
+    mg->shard_hb = world >= 4 ? 1 : 0;
+    hipError_t e = hipSetDevice(h->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&mg->d_infos, (size_t)(world + 1) * sizeof(int));
+    if (e != hipSuccess) { delete mg; return gpk_fail(h, e, "gpk_mg_create", __FILE__, __LINE__); }
+    *out = mg;
+    return 0;
+}
+
+extern "C" int gpk_mg_destroy(gpk_mg_handle mg) {
+    if (!mg) return 0;
+    gpk_handle h = mg->h;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (mg->own_comm && mg->comm && mg->comm_destroy) (void)mg->comm_destroy(mg->comm);
+    for (hipEvent_t e : mg->ev) (void)hipEventDestroy(e);
+    if (mg->ev_begin) (void)hipEventDestroy(mg->ev_begin);
+    if (mg->s_panel) (void)hipStreamDestroy(mg->s_panel);
+    if (mg->s_comm) (void)hipStreamDestroy(mg->s_comm);
+    for (int i = 0; i < 2; ++i) if (mg->buf[i]) (void)hipFree(mg->buf[i]);
+    if (mg->gsend) (void)hipFree(mg->gsend);
+    if (mg->grecv) (void)hipFree(mg->grecv);
+    if (mg->d_infos) (void)hipFree(mg->d_infos);
+    delete mg;                                                        // (the library handle of dlopen stays: RCCL may hold threads)
+    return 0;
+}
+
+extern "C" int gpk_mg_set_comm(gpk_mg_handle mg, void* comm, gpk_mg_bcast_fn bcast, gpk_mg_allgather_fn allgather) {
+    if (!mg || !bcast || !allgather) return GPK_ERR_ARG;
+    mg->comm = comm; mg->bcast = bcast; mg->allgather = allgather; mg->own_comm = false;
+    return 0;
+}
+
+extern "C" int gpk_mg_set_option(gpk_mg_handle mg, int key, int value) {
+    if (!mg) return GPK_ERR_ARG;
+    if (key == 0) { mg->lookahead = value != 0; return 0; }
+    if (key == 1) { mg->shard_hb = value != 0; return 0; }
+    if (key == 2 && value >= 1) { mg->col_align = value; return 0; }
+    return gpk_bad_arg(mg->h, "gpk_mg_set_option: key / value");
+}
+
+extern "C" int gpk_mg_rccl_unique_id(const char* librccl_path, void* host_id128) {
+    if (!host_id128) return GPK_ERR_ARG;
+    void* lib = open_rccl(librccl_path);
+    if (!lib) return GPK_ERR_NODEV;
+    auto get = (int (*)(nccl_unique_id*))dlsym(lib, "ncclGetUniqueId");
+    if (!get) return GPK_ERR_NODEV;
+    const int r = get((nccl_unique_id*)host_id128);
+    return r == 0 ? 0 : -(10000 + r);
+}
+
+extern "C" int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* host_id128) {
+    if (!mg || !host_id128) return GPK_ERR_ARG;
+    gpk_handle h = mg->h;
+    void* lib = open_rccl(librccl_path);
+    if (!lib) { h->err = std::string("gpk_mg_rccl_init: cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return GPK_ERR_NODEV; }
+    auto init = (int (*)(void**, int, nccl_unique_id, int))dlsym(lib, "ncclCommInitRank");
+    auto bc = (gpk_mg_bcast_fn)dlsym(lib, "ncclBroadcast");
+    auto ag = (gpk_mg_allgather_fn)dlsym(lib, "ncclAllGather");
+    mg->comm_destroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    mg->errstr = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!init || !bc || !ag) { h->err = "gpk_mg_rccl_init: ncclCommInitRank / ncclBroadcast / ncclAllGather not found in the library"; return GPK_ERR_NODEV; }
+    GPK_HIP(h, hipSetDevice(h->device));
+    nccl_unique_id id;
+    memcpy(&id, host_id128, sizeof id);
+    void* comm = nullptr;
+    MG_NCCL(mg, init(&comm, mg->world, id, mg->rank), "ncclCommInitRank");
+    mg->lib = lib; mg->comm = comm; mg->bcast = bc; mg->allgather = ag; mg->own_comm = true;
+    return 0;
+}
+
+extern "C" int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info) {
+    if (!mg || !A || n < 0 || lda < n) return GPK_ERR_ARG;
+    gpk_handle h = mg->h;
+    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    GPK_TRY(exec_potrf(mg, A, n, lda));
+    if (host_info) GPK_TRY(gather_info(mg, host_info));
+    return 0;
+}
+
+extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double* z, double step_size, double* S, int lds, double* S2,
+                              double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info) {
+    if (!mg || !p || !z || !S || !Hb || !delta) return GPK_ERR_ARG;
+    gpk_handle h = mg->h;
+    const int P = mg->world, rank = mg->rank, nb = mg->nb;
+    if (P == 1) return gpk_gn_step(h, p, z, step_size, S, lds, Hb, ldh, delta, host_loss_in, host_info);
+    if (p->system != GPK_GN_ELLIPTIC) return gpk_bad_arg(h, "gpk_mg_gn_step: elliptic system only");
+    if (!p->Dinv || !S2) return gpk_bad_arg(h, "gpk_mg_gn_step: needs the inverted diagonal blocks (Dinv) and S2");
+    if (!mg->allgather) return gpk_bad_arg(h, "gpk_mg: world > 1 needs a communicator (gpk_mg_rccl_init / gpk_mg_set_comm)");
+    int nz = 0, rows = 0;
+    GPK_TRY(gpk_i_gn_dims(h, p, &nz, &rows));
+    const int nc = nz + 1;
+    if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gpk_mg_gn_step: lds/ldh < nz+1");
+    const int db = p->dinv_block > 0 ? p->dinv_block : 256;
+    const hipStream_t s = h->stream;
+    // ---- S <- [A | F] in the leading-zero layout on every rank (a memset + O(N)); my column shard of L^{-1}[A | F] -> S2
+    GPK_TRY(gpk_gn_build_rev(h, p, z, S, lds));
+    column_bounds(nc, nz, rows, P, mg->col_align, mg->bounds);
+    const std::vector<int>& b = mg->bounds;
+    const int c0 = b[rank], c1 = b[rank + 1];
+    int per = 0;
+    for (int r = 0; r < P; ++r) per = std::max(per, b[r + 1] - b[r]);
+    if (c1 > c0)
+        GPK_TRY(gpk_i_trsm_left_dinv(h, p->L, p->Dinv, db, rows, p->ldl, S + c0, lds, S2 + c0, lds, c1 - c0, std::max(nz - c0, 0), 0));
+    // ---- all-gather of the column shards (padded to the widest; persistent staging buffers)
+    const size_t shard = (size_t)rows * per;
+    const int nblk = gpk_ceil_div(nc, nb), per_rank = gpk_ceil_div(nblk, P);
+    const size_t hrows = (size_t)per_rank * nb * ldh;
+    GPK_TRY(ensure_gather(mg, std::max(shard, hrows) * sizeof(double), std::max(shard, hrows) * P * sizeof(double)));
+    if (c1 > c0)
+        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)per * 8, S2 + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)rows, hipMemcpyDeviceToDevice, s));
+    MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, shard, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of S");
+    for (int r = 0; r < P; ++r) {
+        const int a0 = b[r], a1 = b[r + 1];
+        if (r == rank || a1 <= a0) continue;
+        GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, mg->grecv + (size_t)r * shard, (size_t)per * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+                                    hipMemcpyDeviceToDevice, s));
+    }
+    // ---- my block rows (cyclic) of the lower triangle of Hb = S2^T S2, structural zeros skipped
+    for (int i = rank; i < nblk; i += P) {
+        const int i0 = i * nb, ib = std::min(nb, nc - i0);
+        GPK_TRY(gpk_i_gemm(h, true, false, ib, i0 + ib, rows, 1.0, S2 + i0, lds, S2, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, nz));
+    }
+    // ---- all-gather of the block rows (each is contiguous: ib x ldh)
+    {
+        int t = 0;
+        for (int i = rank; i < nblk; i += P, ++t) {
+            const int i0 = i * nb, ib = std::min(nb, nc - i0);
+            GPK_HIP(h, hipMemcpyAsync(mg->gsend + (size_t)t * nb * ldh, Hb + (long)i0 * ldh, (size_t)ib * ldh * 8, hipMemcpyDeviceToDevice, s));
+        }
+        MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, hrows, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of Hb");
+        for (int r = 0; r < P; ++r) {
+            if (r == rank) continue;
+            int tt = 0;
+            for (int i = r; i < nblk; i += P, ++tt) {
+                const int i0 = i * nb, ib = std::min(nb, nc - i0);
+                GPK_HIP(h, hipMemcpyAsync(Hb + (long)i0 * ldh, mg->grecv + (size_t)r * hrows + (size_t)tt * nb * ldh, (size_t)ib * ldh * 8,
+                                          hipMemcpyDeviceToDevice, s));
+            }
+        }
+    }
+    double* d_loss = h->d_scalars;
+    GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, s));
+    // ---- Cholesky of the bordered matrix: replicated (every rank factors its own copy, no communication), or panel-sharded
+    //      with the plan of the big factorisation; the last row of the factor is (L_H^{-1} g/2)^T either way
+    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
+    if (mg->shard_hb) GPK_TRY(exec_potrf(mg, Hb, nc, ldh));
+    else GPK_TRY(gpk_i_potrf(h, Hb, nc, ldh, 0));
+    GPK_TRY(gpk_i_gn_finish(h, p, nz, 1, Hb, ldh, S, delta, z, step_size));
+    double loss = 0.0;
+    int info = 0;
+    GPK_HIP(h, hipMemcpyAsync(&loss, d_loss, sizeof(double), hipMemcpyDeviceToHost, s));
+    if (mg->shard_hb) GPK_TRY(gather_info(mg, &info));
+    else {
+        GPK_HIP(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+        GPK_HIP(h, hipStreamSynchronize(s));
+    }
+    if (info == nc) info = 0;                                         // the border pivot is not part of H
+    if (host_info) *host_info = info;
+    if (host_loss_in) *host_loss_in = loss;
+    return 0;
+}

@@ -159,6 +159,11 @@ class ShardedFactorSolve:
         self.col_align = 128                                       # column shards start at multiples of this (tile/vector alignment)
         self._panel = None
 
+    def describe(self, world, dinv_block):
+        return (f'Theta: panel-sharded Cholesky (block-cyclic columns, width {self.nb}, RCCL broadcast); step: column-sharded TRSM '
+                f'(GEMM-only, inverted {dinv_block}-row diagonal blocks of the factor) + all-gather(S) + row-block-sharded SYRK + '
+                f'all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)')
+
     # ------------------------------------------------------------------------------------------------ Cholesky
     def _panel_buf(self, A, rows, cols):
         need = rows * cols
