@@ -520,6 +520,14 @@ def run_sharded(args, workload, steps=None, warmup=None):
     ops = GpuBlockOps(ctx)                                        # libgpk now runs on torch's current stream
     comm = Comm()
     solver = ShardedFactorSolve(ops, comm, nb=args.panel)
+    # Two executors of the same schedule (the plan of gpk_mg_plan_potrf): 'native' (default) = gpk_mg_* behind the C ABI, HIP streams
+    # and events, RCCL called from C on a communicator of its own (unique id shipped through the process group); 'python' =
+    # gpk/sharded.py over torch.distributed collectives (GPK_BENCH_SHARDED=python)
+    engine = os.environ.get('GPK_BENCH_SHARDED', 'native')
+    mgpu = None
+    if engine == 'native':
+        from gpk.mg import MultiGpu
+        mgpu = MultiGpu(ctx, rank, world, panel=args.panel, comm='rccl' if world > 1 else None)
     Xd, Xb, f, g, z0 = synthetic_problem(Nd, Nb)                  # identical on every rank (seeded)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
     tXd, tXb, tf, tg, z = t(Xd), t(Xb), t(f), t(g), t(z0)
@@ -535,7 +543,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
         ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, tXd.data_ptr(), Nd, tXb.data_ptr(), Nb, nugget, 2, Theta.data_ptr(), ld, ratios))
         torch.cuda.synchronize(); asm_ms = 1e3 * (time.perf_counter() - t0)
         t0 = time.perf_counter()
-        info = solver.potrf(Theta, N)
+        info = mgpu.potrf(Theta.data_ptr(), N, ld) if mgpu else solver.potrf(Theta, N)
         torch.cuda.synchronize(); chol_ms = 1e3 * (time.perf_counter() - t0)
         if info == 0 or nugget >= 1e-8:
             break
@@ -555,13 +563,18 @@ def run_sharded(args, workload, steps=None, warmup=None):
     Dinv = ops.trtri_diag(Theta, N, block=gpk.device.dinv_block_for(N))
     torch.cuda.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
     S2 = torch.zeros((N, lds), dtype=torch.float64, device=dev)
+    ps.Dinv, ps.Dinv2, ps.dinv_block = Dinv.data_ptr(), None, gpk.device.dinv_block_for(N)
+    if mgpu:
+        step = lambda: mgpu.gn_step(ps, z.data_ptr(), 1.0, S.data_ptr(), lds, S2.data_ptr(), Hb.data_ptr(), lds, delta.data_ptr())[0]
+    else:
+        step = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
     losses = []
     for _ in range(warmup):
-        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0])
+        losses.append(step())
     comm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses.append(solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0])
+        losses.append(step())
     torch.cuda.synchronize(); comm.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -602,6 +615,8 @@ def run_sharded(args, workload, steps=None, warmup=None):
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
                        'parallelism': solver.describe(world, gpk.device.dinv_block_for(N)),
+                       'executor': (f'native: gpk_mg_potrf / gpk_mg_gn_step (C ABI), collectives = {getattr(mgpu, "comm_kind", "none (one rank)")}'
+                                    if mgpu else 'python: gpk/sharded.py over torch.distributed'),
                        'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step; only the factor of Theta and the inverses of its diagonal '
                                       'blocks are reused across steps); structural zeros of A(z) skipped as on one GPU, column shards cut by '
                                       'work; f1_tflops is the dense-equivalent rate, roofline.achieved the executed one'},
@@ -619,6 +634,8 @@ def run_sharded(args, workload, steps=None, warmup=None):
                                         'frac': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world), 'ms': chol_ms},
             'cpu_baseline': None,
         }
+    if mgpu:
+        mgpu.close()
     del S, S2, Hb, Theta, Dinv
     torch.cuda.empty_cache()
     ctx.close()

@@ -11,7 +11,10 @@
  *     symmetric outputs are stored full.  Vector loads are 16-byte wide when pointer and leading dimension allow
  *     (even ld, 16-byte aligned base); any alignment is accepted.
  *   - calls are asynchronous on the handle's stream; functions that return host scalars (info, loss, ratios)
- *     synchronise that stream.  One host thread per handle; no global mutable state.
+ *     synchronise that stream.  One host thread per handle.  The product entry points of this header and of gpk_mg.h keep
+ *     all mutable state in the handle; the only process-wide state of the library are the DEVELOPMENT switches of
+ *     gpk_debug.h (gpk_debug_set: kernel-variant selection for A/B measurements and tests), which default to the tuned
+ *     configuration, are never touched by the product path and must not be flipped while another thread is inside a call.
  *   - there is NO CPU fallback: without a gfx950 device gpk_create fails.
  */
 #ifndef GPK_H
@@ -99,6 +102,12 @@ int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl, double* B
  * (jnp.linalg.cholesky, src/PDEs.py:77), the owner's share of a step of the panel-sharded multi-GPU factorisation.
  * host_info as gpk_potrf (may be NULL: no host synchronisation then). */
 int gpk_potrf_panel(gpk_handle h, double* A, int nrows, int ncols, int lda, int* host_info);
+/* The same panel step for schedules that must not touch the host per panel (gpk/sharded.py, look-ahead): the pivot status
+ * accumulates in the handle's device-side info word (first failure wins; pivot indices offset by pivot_base = the panel's first
+ * column in the whole matrix).  gpk_info_reset before the first panel, ONE gpk_info_read (synchronises) after the last. */
+int gpk_potrf_panel_at(gpk_handle h, double* A, int nrows, int ncols, int lda, int pivot_base);
+int gpk_info_reset(gpk_handle h);
+int gpk_info_read(gpk_handle h, int* host_info);
 /* X <- X L^{-T} (X is m x n): the panel solve of the blocked Cholesky; exported for the multi-GPU panel-sharded
  * factorisation, whose per-panel schedule lives in the host layer (gpk/sharded.py). */
 int gpk_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);
@@ -192,27 +201,7 @@ int gpk_gn_hessian_grad(gpk_handle h, const gpk_gn_problem* host_prob, const dou
 /* measurement vector(s) F(z) = sol_vec (src/PDEs.py:132-134,338-342,488-497; IP.py:176-186): out (s_rows,) */
 int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* out);
 
-/* development aids (process-wide): key 0 = force the GEMM tile configuration (0 auto, 1 = 128x128, 2 = 64x64);
- * key 2 = run multi-RHS triangular solves as 4 column groups on concurrent streams (0 off, default); key 10 = 0: substitution
- * strips even when Dinv is given; key 12 = 0: SYRK then right-looking Cholesky on one stream instead of the two-partition
- * pipeline; key 13 = CUs of the chain partition (default 32); key 24 = workgroups per split-K product launch of the pipeline
- * (default 1000, 0 = no split); the full list is in tools/README.md */
-int gpk_debug_set(int key, int value);
-/* development aid: enable/disable and read the shader-clock phase stamps of the 64-wide diagonal-block kernels */
-int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable);
-
-/* ---- micro-benchmarks used to fix the roofline denominators ------------------------------------------------ */
-int gpk_ubench_mfma_f64(gpk_handle h, int iters, double* host_tflops);      /* v_mfma_f64_16x16x4_f64 issue rate */
-int gpk_ubench_hbm_write(gpk_handle h, size_t bytes, int iters, double* host_gbps);
-int gpk_ubench_latency(gpk_handle h, int mode, double* host_cycles_per_op);
-int gpk_ubench_xcc_map(gpk_handle h, int nblocks, int mode, int* host_out);   /* XCD id (HW_REG_XCC_ID) each workgroup ran on; mode 1: odd workgroups linger */   /* 0 dep. v_fma_f64, 1 indep. v_fma_f64, 2 dep. ds_read, 3 indep. ds_read, 4 dep. mfma_f64 (shader cycles per op, one wave) */
-/* which CUs a stream created with hipExtStreamCreateWithCUMask(bits [first_bit, first_bit + nbits)) dispatches to: per
- * workgroup XCC_ID | HW_REG_HW_ID << 8 (tools/cu_mask_probe.py) */
-int gpk_ubench_cu_census(gpk_handle h, int first_bit, int nbits, int nblocks, int* host_out);
-/* development probe (tools/overlap_probe.py): C2 <- S^T S on a low-priority side stream while potrf(copy of H) runs on the
- * handle's stream; host_ms3 = {potrf alone, syrk alone, both concurrently}.  Round-1 finding: no overlap (5.5 vs 2.9 + 2.5 ms). */
-int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,
-                            double* host_ms3);
+/* Development switches, phase stamps, probes and the micro-benchmarks behind the roofline denominators: include/gpk_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 #include "../../include/gpk.h"
+#include "../../include/gpk_debug.h"
+#include "../../include/gpk_mg.h"
 
 #define GPK_ERR_ARG (-9001)
 #define GPK_ERR_NODEV (-9002)

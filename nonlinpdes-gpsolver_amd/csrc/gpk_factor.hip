@@ -2215,6 +2215,26 @@ extern "C" int gpk_potrf_panel(gpk_handle h, double* A, int nrows, int ncols, in
     return 0;
 }
 
+// Panel step without any host traffic: the pivot status accumulates in the handle's device-side info word (first failure wins),
+// indices offset by pivot_base; gpk_info_reset before the first panel of a factorisation, ONE gpk_info_read at its end.
+extern "C" int gpk_potrf_panel_at(gpk_handle h, double* A, int nrows, int ncols, int lda, int pivot_base) {
+    if (!h || !A || ncols < 0 || nrows < ncols || lda < ncols || pivot_base < 0) return GPK_ERR_ARG;
+    return gpk_i_potrf_panel(h, A, nrows, ncols, lda, pivot_base);
+}
+
+extern "C" int gpk_info_reset(gpk_handle h) {
+    if (!h) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    return 0;
+}
+
+extern "C" int gpk_info_read(gpk_handle h, int* host_info) {
+    if (!h || !host_info) return GPK_ERR_ARG;
+    GPK_HIP(h, hipMemcpyAsync(host_info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int gpk_trsm(gpk_handle h, int trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
     if (!h || !L || !B || n < 0 || nrhs < 0 || ldl < n || ldb < nrhs) return GPK_ERR_ARG;
     if (nrhs == 1 && ldb == 1) return gpk_i_trsv(h, trans != 0, L, n, ldl, B);

@@ -24,8 +24,22 @@ _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 _pi, _pd, _pvp = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_void_p)
 _pp = C.POINTER(GNProblemStruct)
 
-# name -> (restype, argtypes); one entry per function of include/gpk.h
+# collective entry points of include/gpk_mg.h: exactly the signatures of ncclBroadcast / ncclAllGather
+MG_BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+MG_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+
+# name -> (restype, argtypes); one entry per function of include/gpk.h, include/gpk_mg.h and include/gpk_debug.h
 PROTOTYPES = {
+    'gpk_mg_create': (_i, [_vp, _i, _i, _i, _pvp]),
+    'gpk_mg_destroy': (_i, [_vp]),
+    'gpk_mg_set_comm': (_i, [_vp, _vp, MG_BCAST_FN, MG_ALLGATHER_FN]),
+    'gpk_mg_rccl_unique_id': (_i, [C.c_char_p, _vp]),
+    'gpk_mg_rccl_init': (_i, [_vp, C.c_char_p, _vp]),
+    'gpk_mg_set_option': (_i, [_vp, _i, _i]),
+    'gpk_mg_potrf': (_i, [_vp, _vp, _i, _i, _pi]),
+    'gpk_mg_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _vp, _i, _vp, _pd, _pi]),
+    'gpk_mg_plan_potrf': (_i, [_i, _i, _i, _i, _i, _pi, _i, _pi]),
+    'gpk_mg_column_bounds': (_i, [_i, _i, _i, _i, _i, _pi]),
     'gpk_create': (_i, [_i, _pvp]),
     'gpk_destroy': (_i, [_vp]),
     'gpk_last_error': (C.c_char_p, [_vp]),
@@ -54,6 +68,9 @@ PROTOTYPES = {
     'gpk_tril': (_i, [_vp, _vp, _i, _i]),
     'gpk_symmetrize_lower': (_i, [_vp, _vp, _i, _i]),
     'gpk_potrf_panel': (_i, [_vp, _vp, _i, _i, _i, _pi]),
+    'gpk_potrf_panel_at': (_i, [_vp, _vp, _i, _i, _i, _i]),
+    'gpk_info_reset': (_i, [_vp]),
+    'gpk_info_read': (_i, [_vp, _pi]),
     'gpk_trsm': (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
     'gpk_trsm_lz': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i]),
     'gpk_trtri_diag': (_i, [_vp, _vp, _i, _i, _vp, _i]),

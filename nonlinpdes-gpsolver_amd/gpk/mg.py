@@ -1,0 +1,168 @@
+"""Binding of include/gpk_mg.h: the native multi-GPU schedule (one process per GPU) -- panel-sharded Cholesky with look-ahead
+and the column-sharded Gauss-Newton step, RCCL reached from C through dlopen.
+
+Python's part is plumbing only: it ships the 128-byte ncclUniqueId from rank 0 to the other ranks (torch.distributed, any
+backend) and hands raw device pointers to the library.  On a one-GPU test box, where RCCL refuses several ranks on one
+device, `comm='staged'` binds host-staged stand-ins for ncclBroadcast / ncclAllGather (torch.distributed over gloo) to the
+same entry points, so that the native schedule itself runs unchanged.
+
+`plan_potrf` / `column_bounds` are pure host functions of the library (no GPU needed): the schedule as data.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._lib import GpkError, MG_ALLGATHER_FN, MG_BCAST_FN, load_library
+
+OP_NAMES = {0: 'FACTOR', 1: 'PACK', 2: 'BCAST', 3: 'UNPACK', 4: 'UPDATE', 5: 'RECORD', 6: 'WAIT'}
+FACTOR, PACK, BCAST, UNPACK, UPDATE, RECORD, WAIT = range(7)
+_DTYPE_BYTES = {0: 1, 1: 1, 2: 4, 3: 4, 4: 8, 5: 8, 6: 2, 7: 4, 8: 8}        # ncclDataType_t -> bytes
+
+
+def plan_potrf(n, nb, world, rank, lookahead=True):
+    """The schedule of the panel-sharded Cholesky for one rank: list of (kind, a, b, stream) -- see gpk_mg.h."""
+    lib = load_library()
+    cnt = C.c_int()
+    rc = lib.gpk_mg_plan_potrf(int(n), int(nb), int(world), int(rank), int(bool(lookahead)), None, 0, C.byref(cnt))
+    if rc != 0:
+        raise GpkError(f'gpk_mg_plan_potrf: invalid arguments ({rc})')
+    buf = (C.c_int * (4 * max(cnt.value, 1)))()
+    lib.gpk_mg_plan_potrf(int(n), int(nb), int(world), int(rank), int(bool(lookahead)), buf, cnt.value, C.byref(cnt))
+    return [tuple(buf[4 * i:4 * i + 4]) for i in range(cnt.value)]
+
+
+def column_bounds(ncols, lead, rows, world, align=128):
+    """Work-balanced contiguous column shards of the leading-zero right-hand side (world + 1 boundaries)."""
+    lib = load_library()
+    out = (C.c_int * (world + 1))()
+    rc = lib.gpk_mg_column_bounds(int(ncols), int(lead), int(rows), int(world), int(align), out)
+    if rc != 0:
+        raise GpkError(f'gpk_mg_column_bounds: invalid arguments ({rc})')
+    return list(out)
+
+
+def torch_rccl_path():
+    """The RCCL library this process already uses: torch bundles one (torch/lib/librccl.so); else the ROCm one."""
+    try:
+        import torch
+        p = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        if os.path.exists(p):
+            return p
+    except Exception:
+        pass
+    for p in ('/opt/rocm/lib/librccl.so.1', '/opt/rocm/lib/librccl.so'):
+        if os.path.exists(p):
+            return p
+    return None
+
+
+class MultiGpu:
+    """gpk_mg_handle of this rank.  comm: 'rccl' (own communicator, unique id exchanged over torch.distributed), 'staged'
+    (host-staged collectives over torch.distributed -- tests on one GPU), or None for world == 1."""
+
+    def __init__(self, ctx, rank=0, world=1, panel=512, comm=None, group=None):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.rank, self.world, self.panel = int(rank), int(world), int(panel)
+        h = C.c_void_p()
+        ctx._chk(self.lib.gpk_mg_create(ctx.h, self.rank, self.world, self.panel, C.byref(h)))
+        self.h = h
+        self._keep = []
+        if self.world > 1:
+            if comm == 'rccl':
+                self._init_rccl(group)
+            elif comm == 'staged':
+                self._init_staged(group)
+            else:
+                raise ValueError("world > 1 needs comm='rccl' or comm='staged'")
+
+    # ---- communicators ------------------------------------------------------------------------------------------------
+    def _init_rccl(self, group):
+        import torch
+        import torch.distributed as dist
+        path = torch_rccl_path()
+        pb = path.encode() if path else None
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            rc = self.lib.gpk_mg_rccl_unique_id(pb, uid)
+            if rc != 0:
+                raise GpkError(f'gpk_mg_rccl_unique_id failed ({rc}); library {path}')
+        box = [bytes(uid.raw) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)      # 128 bytes through the process group's own transport
+        uid2 = (C.c_char * 128).from_buffer_copy(box[0])
+        self.ctx._chk(self.lib.gpk_mg_rccl_init(self.h, pb, uid2))
+        self.comm_kind = f'rccl ({path})'
+
+    def _init_staged(self, group):
+        """ncclBroadcast / ncclAllGather stand-ins: wait for the stream, stage through host memory, torch.distributed (gloo)."""
+        import torch
+        import torch.distributed as dist
+        hip = C.CDLL('libamdhip64.so')
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        rank, world = self.rank, self.world
+
+        def bcast(send, recv, count, dtype, root, comm, stream):
+            try:
+                nbytes = count * _DTYPE_BYTES[dtype]
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                host = np.empty(nbytes, dtype=np.uint8)
+                if rank == root and hip.hipMemcpy(host.ctypes.data, send, nbytes, 2) != 0:
+                    return 1
+                t = torch.from_numpy(host)
+                dist.broadcast(t, src=root, group=group)
+                if rank != root and hip.hipMemcpy(recv, host.ctypes.data, nbytes, 1) != 0:
+                    return 1
+                return 0
+            except Exception:                                     # noqa: BLE001 -- a C caller cannot take an exception
+                return 3
+
+        def allgather(send, recv, count, dtype, comm, stream):
+            try:
+                nbytes = count * _DTYPE_BYTES[dtype]
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 1
+                host = np.empty(nbytes, dtype=np.uint8)
+                if hip.hipMemcpy(host.ctypes.data, send, nbytes, 2) != 0:
+                    return 1
+                outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(outs, torch.from_numpy(host), group=group)
+                allb = torch.cat(outs).numpy()
+                if hip.hipMemcpy(recv, allb.ctypes.data, nbytes * world, 1) != 0:
+                    return 1
+                return 0
+            except Exception:                                     # noqa: BLE001
+                return 3
+
+        self._keep = [MG_BCAST_FN(bcast), MG_ALLGATHER_FN(allgather)]
+        self.ctx._chk(self.lib.gpk_mg_set_comm(self.h, None, self._keep[0], self._keep[1]))
+        self.comm_kind = 'host-staged stand-ins over torch.distributed'
+
+    # ---- options / calls ----------------------------------------------------------------------------------------------
+    def set_option(self, key, value):
+        keys = {'lookahead': 0, 'shard_hb': 1, 'col_align': 2}
+        self.ctx._chk(self.lib.gpk_mg_set_option(self.h, keys[key] if isinstance(key, str) else int(key), int(value)))
+
+    def potrf(self, A_ptr, n, lda):
+        """In-place lower Cholesky over all ranks (A replicated on entry, the full factor on every rank on return) -> info"""
+        info = C.c_int()
+        self.ctx._chk(self.lib.gpk_mg_potrf(self.h, A_ptr, int(n), int(lda), C.byref(info)))
+        return self.ctx._chk_info(info.value)
+
+    def gn_step(self, prob_struct, z_ptr, step_size, S_ptr, lds, S2_ptr, Hb_ptr, ldh, delta_ptr):
+        loss, info = C.c_double(), C.c_int()
+        self.ctx._chk(self.lib.gpk_mg_gn_step(self.h, C.byref(prob_struct), z_ptr, float(step_size), S_ptr, int(lds), S2_ptr, Hb_ptr, int(ldh),
+                                              delta_ptr, C.byref(loss), C.byref(info)))
+        return loss.value, self.ctx._chk_info(info.value)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.gpk_mg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

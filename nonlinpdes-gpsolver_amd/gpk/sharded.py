@@ -1,27 +1,37 @@
-"""Multi-GPU (one process per GPU) schedule of the factor/solve path for the >=10k-point configuration.
+"""Multi-GPU (one process per GPU) schedule of the factor/solve path for the >=10k-point configuration, driven from Python
+over torch.distributed (INTEGRATION.md route A; the same schedule natively behind the C ABI: gpk/mg.py, include/gpk_mg.h).
 
-Only the SCHEDULE lives here (which rank factors which panel, what is broadcast, who updates which block column); every
-flop runs in libgpk.so through the `ops` object, and every exchange is a torch.distributed collective on the process
-group it is given (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the CPU tests, which inject a numpy `ops`).
+Only the SCHEDULE is interpreted here; every flop runs in libgpk.so through the `ops` object, and every exchange is a
+torch.distributed collective on the process group it is given (backend "nccl" = RCCL over xGMI on the GPU box; "gloo" in the
+CPU tests, which inject a numpy `ops`).
 
-Cholesky (Theta, and the bordered Gauss-Newton matrix Hb):  1-D block-cyclic BLOCK-COLUMN distribution, panel width nb.
-    for k in panels:  owner = k mod P
-        owner:   potrf(diagonal block), rows below <- rows * L_kk^{-T}          (gpk_potrf, gpk_trsm_right_lt)
-        all:     broadcast the factored panel ((n - k nb) x nb) from its owner   (ncclBroadcast)
-        all:     store the panel (every rank ends up with the full L: HBM is 288 GB, Theta is 9.2 GB at C5)
-        rank r:  update the block columns j > k with j mod P == r                (gpk_gemm, MFMA)
+Cholesky (Theta, and optionally the bordered Gauss-Newton matrix Hb): 1-D block-cyclic BLOCK-COLUMN distribution, panel width
+nb.  The schedule is NOT written down here: it is the plan libgpk returns (gpk_mg_plan_potrf, a pure host function; the
+native executor gpk_mg_potrf runs the very same list) -- a flat list of operations on three streams with explicit events:
+    FACTOR k   the owner (k mod P) factors its tall panel in place          (gpk_potrf_panel_at, fused panel kernels)
+    PACK / BCAST / UNPACK k   contiguous image of the panel, ncclBroadcast, copy into every other rank's matrix
+                              (all ranks end up with the full L: HBM is 288 GB, Theta is 9.2 GB at config 5)
+    UPDATE j,k  the owner of block column j applies panel k to it            (gpk_gemm, MFMA)
+    RECORD / WAIT e           dependencies between the streams
+With look-ahead (default for P > 1) the owner of panel k+1 applies panel k to that column and factors it on a high-priority
+stream as soon as panel k has arrived, and the broadcast of k+1 travels on a communication stream while every rank still
+applies panel k to its other columns.  No host synchronisation per panel: the pivot status stays on the device
+(gpk_info_reset / gpk_info_read) and is read ONCE at the end.
 Gauss-Newton step:  S = L^{-1}[A | F] is independent per right-hand-side column -> rank r solves its column range with
-    the replicated L (no communication), the column shards are all-gathered (every rank needs all of S for its rows of
-    Hb = S^T S), block rows of Hb are computed cyclically and all-gathered, Hb is factored REPLICATED on every rank (cheaper
-    than the panel scheme at this size, see gn_step) and the small triangular solve + update are replicated, so all ranks
-    hold the same iterate bit for bit.
+    the replicated L (no communication), the column shards are all-gathered through persistent staging buffers (every rank
+    needs all of S for its rows of Hb = S^T S), block rows of Hb are computed cyclically and all-gathered, Hb is factored
+    replicated (P <= 2: cheaper than any exchange) or with the plan above (P >= 4), and the small triangular solve + update
+    are replicated, so all ranks hold the same iterate bit for bit.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a panel broadcast moves <= 139 MB at C5, the S all-gather 4.35 GB
 in total, Hb 2 GB; nothing here is a ring all-reduce.
 """
+import contextlib
 import ctypes as C
 
 import torch
 import torch.distributed as dist
+
+from . import mg as _mg
 
 
 class Comm:
@@ -33,22 +43,44 @@ class Comm:
         self.rank = dist.get_rank(group) if self.on else 0
         self.world = dist.get_world_size(group) if self.on else 1
 
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == 'gloo'
+
     def broadcast(self, t, src):
         if self.world > 1:
+            if self._staged(t):                                    # tests: several ranks on ONE GPU, gloo moves host memory
+                torch.cuda.current_stream().synchronize()
             dist.broadcast(t, src=src, group=self.group)
 
-    def all_gather(self, outs, t):
+    def all_gather_into(self, out, t):
+        """out: (world * t.numel(),) contiguous; t: contiguous"""
         if self.world == 1:
-            outs[0].copy_(t)
-        elif t.is_cuda and dist.get_backend(self.group) == 'gloo':
+            out.copy_(t.reshape(-1))
+        elif self._staged(t):
             # gloo has no all_gather for device tensors (it is only used for tests: several ranks sharing ONE GPU);
             # emulate it with one broadcast per rank
+            n = t.numel()
+            torch.cuda.current_stream().synchronize()
             for r in range(self.world):
+                part = out[r * n:(r + 1) * n]
                 if r == self.rank:
-                    outs[r].copy_(t)
-                dist.broadcast(outs[r], src=r, group=self.group)
+                    part.copy_(t.reshape(-1))
+                    torch.cuda.current_stream().synchronize()
+                dist.broadcast(part, src=r, group=self.group)
         else:
-            dist.all_gather(outs, t, group=self.group)
+            dist.all_gather_into_tensor(out, t.reshape(-1), group=self.group)
+
+    def first_failure(self, info, device):
+        """LAPACK info over all ranks: the smallest positive index (every rank saw only the panels it factored); a negative
+        value (device-side wait expired) anywhere wins."""
+        if self.world == 1:
+            return int(info)
+        big = 1 << 40
+        key = -big if info < 0 else (int(info) if info > 0 else big)
+        t = torch.tensor([key], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        v = int(t.item())
+        return -1 if v == -big else (0 if v == big else v)
 
     def max_int(self, v, device):
         if self.world == 1:
@@ -83,6 +115,49 @@ class GpuBlockOps:
         self.stream = torch.cuda.Stream()
         torch.cuda.set_stream(self.stream)
         ctx._chk(self.lib.gpk_set_stream(self.h, C.c_void_p(self.stream.cuda_stream)))
+        self._side = None
+
+    # ---- streams and events of the look-ahead schedule --------------------------------------------------------------
+    def streams(self, lookahead):
+        """(main, panel, communication): the two side streams are high-priority torch streams, created once"""
+        if not lookahead:
+            return (self.stream, self.stream, self.stream)
+        if self._side is None:
+            self._side = (torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=-1))
+        for s in self._side:                                       # what is in the matrix was produced on the main stream
+            s.wait_stream(self.stream)
+        return (self.stream, self._side[0], self._side[1])
+
+    @contextlib.contextmanager
+    def on(self, stream):
+        """run libgpk and torch on `stream` inside the block"""
+        prev = torch.cuda.current_stream()
+        if stream == prev:
+            yield
+            return
+        torch.cuda.set_stream(stream)
+        self.ctx._chk(self.lib.gpk_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+        try:
+            yield
+        finally:
+            torch.cuda.set_stream(prev)
+            self.ctx._chk(self.lib.gpk_set_stream(self.h, C.c_void_p(prev.cuda_stream)))
+
+    def record(self):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def wait(self, ev):
+        torch.cuda.current_stream().wait_event(ev)
+
+    def info_reset(self):
+        self.ctx._chk(self.lib.gpk_info_reset(self.h))
+
+    def info_read(self):
+        info = C.c_int()
+        self.ctx._chk(self.lib.gpk_info_read(self.h, C.byref(info)))
+        return info.value
 
     @staticmethod
     def _p(T, r=0, c=0):
@@ -94,10 +169,9 @@ class GpuBlockOps:
         return self.ctx._chk_info(info.value)
 
     def potrf_panel(self, A, r0, n, nrows):
-        """A[r0:r0+nrows, r0:r0+n]: factor the diagonal block and solve the rows below against it (one fused panel step)"""
-        info = C.c_int()
-        self.ctx._chk(self.lib.gpk_potrf_panel(self.h, self._p(A, r0, r0), nrows, n, A.stride(0), C.byref(info)))
-        return self.ctx._chk_info(info.value)
+        """A[r0:r0+nrows, r0:r0+n]: factor the diagonal block and solve the rows below against it (one fused panel step); the
+        pivot status goes to the device-side info word (index relative to the whole matrix), no host synchronisation"""
+        self.ctx._chk(self.lib.gpk_potrf_panel_at(self.h, self._p(A, r0, r0), nrows, n, A.stride(0), int(r0)))
 
     def trsm_right(self, A, r0, n, row0, m):
         """A[row0:row0+m, r0:r0+n] <- A[...] * L^{-T} with L = A[r0:r0+n, r0:r0+n]"""
@@ -153,53 +227,84 @@ def _ceil_div(a, b):
 
 
 class ShardedFactorSolve:
-    def __init__(self, ops, comm, nb=512):
+    def __init__(self, ops, comm, nb=512, lookahead=None, shard_hb=None):
+        """lookahead: None = on for more than one rank; shard_hb: None = the Cholesky of Hb is panel-sharded from 4 ranks on
+        (replicated below: every rank factors its own copy, no communication)."""
         self.ops, self.comm, self.nb = ops, comm, int(nb)
         self.rank, self.P = comm.rank, comm.world
+        self.lookahead = (self.P > 1) if lookahead is None else bool(lookahead)
+        self.shard_hb = (self.P >= 4) if shard_hb is None else bool(shard_hb)
         self.col_align = 128                                       # column shards start at multiples of this (tile/vector alignment)
-        self._panel = None
+        self._panel = [None, None]                                 # transfer buffers of the panel broadcasts (slot = panel mod 2)
+        self._stage = {}                                           # persistent all-gather staging buffers, by name
+        self.trace = None                                          # tests: set to a list to record the operations as issued
 
     def describe(self, world, dinv_block):
-        return (f'Theta: panel-sharded Cholesky (block-cyclic columns, width {self.nb}, RCCL broadcast); step: column-sharded TRSM '
+        hb = 'panel-sharded POTRF(Hb) with the same plan' if self.shard_hb else 'replicated POTRF(Hb)'
+        la = ('with look-ahead (next panel factored and broadcast on side streams while the trailing updates run)'
+              if self.lookahead else 'no look-ahead')
+        return (f'Theta: panel-sharded Cholesky (block-cyclic columns, width {self.nb}, RCCL broadcast, {la}); step: column-sharded TRSM '
                 f'(GEMM-only, inverted {dinv_block}-row diagonal blocks of the factor) + all-gather(S) + row-block-sharded SYRK + '
-                f'all-gather(Hb) + replicated POTRF(Hb)/TRSV over {world} rank(s)')
+                f'all-gather(Hb) + {hb} + replicated TRSV over {world} rank(s)')
+
+    # ------------------------------------------------------------------------------------------------ buffers
+    def _panel_buf(self, slot, like, count):
+        b = self._panel[slot]
+        if b is None or b.numel() < count or b.device != like.device:
+            b = torch.empty(count, dtype=torch.float64, device=like.device)
+            self._panel[slot] = b
+        return b
+
+    def _staging(self, name, like, count):
+        b = self._stage.get(name)
+        if b is None or b.numel() < count or b.device != like.device:
+            b = torch.empty(count, dtype=torch.float64, device=like.device)
+            self._stage[name] = b
+        return b[:count]
 
     # ------------------------------------------------------------------------------------------------ Cholesky
-    def _panel_buf(self, A, rows, cols):
-        need = rows * cols
-        if self._panel is None or self._panel.numel() < need or self._panel.device != A.device:
-            self._panel = torch.empty(need, dtype=torch.float64, device=A.device)
-        return self._panel[:need].view(rows, cols)
-
     def potrf(self, A, n):
         """In-place lower Cholesky of A[:n, :n] (row-major torch tensor, any leading dimension), panels owned
-        block-cyclically; on return every rank holds the complete factor.  Returns LAPACK-style info (max over ranks)."""
+        block-cyclically; on return every rank holds the complete factor.  Returns LAPACK-style info (identical on all ranks)."""
         nb, P, rank, ops = self.nb, self.P, self.rank, self.ops
         nblk = _ceil_div(n, nb)
-        info = 0
-        for k in range(nblk):
+        la = self.lookahead and nblk > 1
+        plan = _mg.plan_potrf(n, nb, P, rank, la)
+        have_streams = hasattr(ops, 'streams')
+        streams = ops.streams(la) if have_streams else (None, None, None)
+        on = ops.on if have_streams else (lambda s: contextlib.nullcontext())
+        events = {}
+        if hasattr(ops, 'info_reset'):
+            ops.info_reset()
+        cap = n * min(nb, n)                                       # panel 0 is the largest
+        for kind, a, b, s in plan:
+            if self.trace is not None:
+                self.trace.append((_mg.OP_NAMES[kind], a, b, s))
+            k = b if kind == _mg.UPDATE else a
             k0 = k * nb
             kb = min(nb, n - k0)
-            below = n - (k0 + kb)
-            owner = k % P
-            panel = self._panel_buf(A, n - k0, kb)
-            if rank == owner:
-                i = ops.potrf_panel(A, k0, kb, n - k0)             # diagonal block + the rows below, fused panel kernels
-                if i and not info:
-                    info = k0 + i
-                if P > 1:
-                    panel.copy_(A[k0:n, k0:k0 + kb])
-            if P > 1:
-                self.comm.broadcast(panel, owner)
-                if rank != owner:
-                    A[k0:n, k0:k0 + kb].copy_(panel)
-            for j in range(k + 1, nblk):                       # right-looking update of MY block columns
-                if j % P != rank:
-                    continue
-                j0 = j * nb
-                jb = min(nb, n - j0)
-                ops.update_nt(A, j0, j0, n - j0, jb, kb, A, j0, k0, A, j0, k0)
-        return self.comm.max_int(info, A.device)
+            with on(streams[s]):
+                if kind == _mg.FACTOR:
+                    ops.potrf_panel(A, k0, kb, n - k0)             # diagonal block + the rows below, fused panel kernels
+                elif kind == _mg.PACK:
+                    self._panel_buf(k & 1, A, cap)[:(n - k0) * kb].view(n - k0, kb).copy_(A[k0:n, k0:k0 + kb])
+                elif kind == _mg.BCAST:
+                    self.comm.broadcast(self._panel_buf(k & 1, A, cap)[:(n - k0) * kb], b)
+                elif kind == _mg.UNPACK:
+                    A[k0:n, k0:k0 + kb].copy_(self._panel_buf(k & 1, A, cap)[:(n - k0) * kb].view(n - k0, kb))
+                elif kind == _mg.UPDATE:
+                    j0 = a * nb
+                    jb = min(nb, n - j0)
+                    ops.update_nt(A, j0, j0, n - j0, jb, kb, A, j0, k0, A, j0, k0)
+                elif kind == _mg.RECORD:
+                    events[a] = ops.record() if have_streams else True
+                elif kind == _mg.WAIT:
+                    if have_streams:
+                        ops.wait(events[a])
+                    else:
+                        assert events.get(a), 'plan waits for an event that was never recorded'
+        info = ops.info_read() if hasattr(ops, 'info_read') else 0     # ONE host read for the whole factorisation
+        return self.comm.first_failure(info, A.device)
 
     # ------------------------------------------------------------------------------------------------ GN step
     def column_range(self, ncols):
@@ -210,18 +315,9 @@ class ShardedFactorSolve:
 
     def column_ranges_lz(self, ncols, lead, rows):
         """Contiguous column shards of equal WORK for the leading-zero right-hand side: column c < lead starts at row
-        lead-1-c, so its forward solve costs ~(rows - start)^2.  Returns the P+1 boundaries (multiples of 128)."""
-        import numpy as np
-        c = np.arange(ncols)
-        start = np.maximum(0, lead - 1 - c)
-        w = np.cumsum((rows - start).astype(np.float64) ** 2)
-        bounds = [0]
-        for r in range(1, self.P):
-            cut = int(np.searchsorted(w, w[-1] * r / self.P))
-            cut = min(max(_ceil_div(cut, self.col_align) * self.col_align, bounds[-1]), ncols)
-            bounds.append(cut)
-        bounds.append(ncols)
-        return bounds
+        lead-1-c, so its forward solve costs ~(rows - start)^2.  Returns the P+1 boundaries (multiples of col_align);
+        computed by the library (gpk_mg_column_bounds: the native step uses the same function)."""
+        return _mg.column_bounds(ncols, lead, rows, self.P, self.col_align)
 
     def gn_step(self, prob_struct, nz, rows, L, z, S, Hb, delta, step_size, rev=False, Dinv=None, S2=None):
         """One Gauss-Newton step with S column-sharded and Hb row-block-sharded; z is updated identically on all ranks.
@@ -252,16 +348,15 @@ class ShardedFactorSolve:
         if use_dinv:
             S = S2                                                 # the solved block lives in S2 from here on
         if P > 1:                                                  # all-gather the column shards of S (padded to the widest)
-            mine = torch.zeros((rows, per), dtype=torch.float64, device=S.device)
+            mine = self._staging('s_send', S, rows * per).view(rows, per)
             if c1 > c0:
                 mine[:, :c1 - c0].copy_(S[:, c0:c1])
-            parts = [torch.empty_like(mine) for _ in range(P)]
-            comm.all_gather(parts, mine)
+            allp = self._staging('s_recv', S, P * rows * per)
+            comm.all_gather_into(allp, mine)
             for r in range(P):
                 a, b = bounds[r], bounds[r + 1]
                 if r != rank and b > a:
-                    S[:, a:b].copy_(parts[r][:, :b - a])
-            del parts, mine
+                    S[:, a:b].copy_(allp[r * rows * per:(r + 1) * rows * per].view(rows, per)[:, :b - a])
         # Hb = S^T S, lower block rows i (cyclic over ranks): Hb[i-block, 0:(i+1)nb]
         nblk = _ceil_div(nc, nb)
         for i in range(nblk):
@@ -276,31 +371,33 @@ class ShardedFactorSolve:
         if P > 1:                                                  # all-gather the block rows (padded to equal counts)
             per_rank = _ceil_div(nblk, P)
             width = Hb.stride(0)
-            mine = torch.zeros((per_rank * nb, width), dtype=torch.float64, device=Hb.device)
+            mine = self._staging('h_send', Hb, per_rank * nb * width).view(per_rank * nb, width)
             for t, i in enumerate(range(rank, nblk, P)):
                 i0 = i * nb; ib = min(nb, nc - i0)
                 mine[t * nb:t * nb + ib, :nc].copy_(Hb[i0:i0 + ib, :nc])
-            parts = [torch.empty_like(mine) for _ in range(P)]
-            comm.all_gather(parts, mine)
+            allp = self._staging('h_recv', Hb, P * per_rank * nb * width)
+            comm.all_gather_into(allp, mine)
             for r in range(P):
                 if r == rank:
                     continue
+                part = allp[r * per_rank * nb * width:(r + 1) * per_rank * nb * width].view(per_rank * nb, width)
                 for t, i in enumerate(range(r, nblk, P)):
                     i0 = i * nb; ib = min(nb, nc - i0)
-                    Hb[i0:i0 + ib, :nc].copy_(parts[r][t * nb:t * nb + ib, :nc])
-            del parts, mine
-        loss_in = float(Hb[nz, nz].item())
-        # Every rank now holds all of Hb and factors it locally (replicated, no communication): at n_z = 16000 one GPU
-        # needs ~37 ms (27 ms of GEMM + the 250-panel latency chain), while the panel-broadcast scheme pays per 512-wide
-        # panel an owner-only factorisation (~0.9 ms) and a broadcast (~0.4 ms) on top of update/P -- 32 panels cost
-        # more than the replicated factorisation at every P >= 2.  (Theta itself is factored once with the sharded scheme.)
-        info = ops.potrf(Hb, 0, nc)                                # bordered: last row of the factor = L_H^{-1} g / 2
+                    Hb[i0:i0 + ib, :nc].copy_(part[t * nb:t * nb + ib, :nc])
+        loss_dev = Hb[nz, nz].clone()                              # read on the host at the END of the step (one synchronisation)
+        # Cholesky of the bordered matrix.  Replicated (every rank factors its own copy, no communication): at n_z = 16000 one GPU
+        # needs ~37 ms, while the panel scheme pays per 512-wide panel an owner-only factorisation and a broadcast on top of
+        # update/P -- with look-ahead those hide behind the updates, which is why from 4 ranks on the plan of the big
+        # factorisation is used for Hb as well (shard_hb).  The last row of the factor is (L_H^{-1} g / 2)^T either way.
+        if self.shard_hb and P > 1:
+            info = self.potrf(Hb, nc)
+        else:
+            info = comm.max_int(ops.potrf(Hb, 0, nc), Hb.device)
         if info == nc:
             info = 0                                               # the border pivot is not part of H
-        info = comm.max_int(info, Hb.device)
         delta.copy_(Hb[nz, :nz])
         ops.trsv(Hb, nz, delta, True)                              # replicated: L_H^{-T} y
         if rev:
             delta.copy_(torch.flip(delta, dims=[0]))               # back to the natural order of the unknowns
         ops.axpy(nz, -float(step_size), delta, z)
-        return loss_in, info
+        return float(loss_dev.item()), info

@@ -8,6 +8,13 @@ from scipy.linalg import solve_triangular
 class NumpyBlockOps:
     def __init__(self, oracle_system=None):
         self.sys = oracle_system
+        self.info = 0                                         # the device-side info word of the real handle
+
+    def info_reset(self):
+        self.info = 0
+
+    def info_read(self):
+        return self.info
 
     def potrf(self, A, r0, n):
         a = A.numpy()
@@ -24,6 +31,8 @@ class NumpyBlockOps:
         info = self.potrf(A, r0, n)
         if nrows > n and info == 0:
             self.trsm_right(A, r0, n, r0 + n, nrows - n)
+        if info and not self.info:
+            self.info = r0 + info                             # first failure wins, index relative to the whole matrix
         return info
 
     def trsm_right(self, A, r0, n, row0, m):

@@ -1,0 +1,180 @@
+"""The native multi-GPU entry points (include/gpk_mg.h) through ctypes on the one GPU of the test box.
+
+  * world 1: gpk_mg_gn_step IS gpk_gn_step (bit for bit); gpk_mg_potrf with the look-ahead plan forced on -- three HIP
+    streams and the event dependencies of the plan on real hardware -- against the oracle's factor, LAPACK info on a bad pivot;
+    the RCCL binding (dlopen of the library torch uses, ncclGetUniqueId, ncclCommInitRank with one rank) comes up;
+  * world 2 and 3: several processes share the GPU (RCCL refuses that), so ncclBroadcast / ncclAllGather are replaced by
+    host-staged stand-ins over gloo bound to the SAME entry points (gpk.mg.MultiGpu(comm='staged')): the native schedule --
+    plan executor with look-ahead, column shards, all-gathers, replicated and panel-sharded Cholesky of Hb -- runs unchanged and
+    must reproduce the oracle's Gauss-Newton iterates, identically on every rank.
+"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _problem(Nd, Nb, seed, nugget=1e-7):
+    rng = np.random.RandomState(seed)
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    Theta = O.add_nugget(O.gram_matrix_assembly(Xd, Xb), 'Nonlinear_elliptic', Nd, Nb, nugget)[0]
+    return Xd, Xb, f, g, Theta, rng.normal(size=Nd)
+
+
+def test_world1_gn_step_is_gpk_gn_step_bit_for_bit():
+    import gpk
+    from gpk.mg import MultiGpu
+    Nd, Nb = 700, 100
+    Xd, Xb, f, g, Theta, z0 = _problem(Nd, Nb, 5)
+    ctx = gpk.Context(0)
+    T = ctx.array(Theta)
+    assert ctx.potrf(T) == 0
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0)
+    S, H, delta, _ = prob.workspace()
+    za, zb = ctx.array(z0), ctx.array(z0)
+    mgpu = MultiGpu(ctx, 0, 1, panel=256)
+    S2 = ctx.empty(S.rows, S.cols, S.ld); S2.zero()
+    for _ in range(3):
+        la, ia = ctx.gn_step(prob, za)
+        lb, ib = mgpu.gn_step(prob.struct, zb.ptr, 1.0, S.ptr, S.ld, S2.ptr, H.ptr, H.ld, delta.ptr)
+        assert la == lb and ia == ib == 0
+        assert np.array_equal(za.download(), zb.download())
+    mgpu.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize('lookahead', [0, 1])
+def test_world1_potrf_plan_executor(lookahead):
+    import gpk
+    from gpk.mg import MultiGpu
+    Nd, Nb = 900, 124                                             # order 1924: 8 panels of 256 (ragged last one)
+    _, _, _, _, Theta, _ = _problem(Nd, Nb, 6)
+    N = Theta.shape[0]
+    ctx = gpk.Context(0)
+    mgpu = MultiGpu(ctx, 0, 1, panel=256)
+    mgpu.set_option('lookahead', lookahead)
+    Lref = O.cholesky(Theta)
+    for rep in range(3):                                          # repeated: events and streams are reused
+        A = ctx.array(Theta)
+        assert mgpu.potrf(A.ptr, N, A.ld) == 0
+        got = np.tril(A.download())
+        assert np.max(np.abs(got - Lref)) <= 1e-9 * np.max(np.abs(Lref))
+        A.free()
+    bad = Theta.copy()
+    bad[1500, 1500] = -1.0                                        # a non-positive pivot in the sixth panel
+    A = ctx.array(bad)
+    assert mgpu.potrf(A.ptr, N, A.ld) == 1501
+    mgpu.close()
+    ctx.close()
+
+
+def test_rccl_binding_comes_up_with_one_rank():
+    """dlopen of the RCCL library this process uses, ncclGetUniqueId, ncclCommInitRank(nranks = 1) on the handle's device, the two
+    collectives bound: what bench.py does on every rank of the 8-GPU run, minus the peers."""
+    import ctypes as C
+    import gpk
+    from gpk.mg import torch_rccl_path
+    ctx = gpk.Context(0)
+    path = torch_rccl_path()
+    assert path is not None
+    uid = (C.c_char * 128)()
+    assert ctx.lib.gpk_mg_rccl_unique_id(path.encode(), uid) == 0
+    assert any(b != 0 for b in uid.raw)
+    h = C.c_void_p()
+    assert ctx.lib.gpk_mg_create(ctx.h, 0, 1, 512, C.byref(h)) == 0
+    rc = ctx.lib.gpk_mg_rccl_init(h, path.encode(), uid)
+    assert rc == 0, ctx.lib.gpk_last_error(ctx.h).decode()
+    assert ctx.lib.gpk_mg_destroy(h) == 0
+    ctx.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    ROOT = {root!r}
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
+    import torch, torch.distributed as dist
+    import gpk
+    from gpk.mg import MultiGpu
+    from oracle import gp_oracle as O
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(21)
+    Nd, Nb = 500, 80
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    sysm = O.EllipticSystem(1.0, 3.0, f, g)
+    Theta = O.add_nugget(O.gram_matrix_assembly(Xd, Xb), 'Nonlinear_elliptic', Nd, Nb, 1e-7)[0]
+    N, nz = 2 * Nd + Nb, Nd
+    Lref = O.cholesky(Theta)
+    z0 = rng.normal(size=nz)
+    sol_ref, hist_ref = O.gn_method(sysm, [Lref], z0, 3, 1)
+    mgpu = MultiGpu(ctx, rank, world, panel=128, comm='staged')
+    mgpu.set_option('col_align', 64)
+    results = []
+    for lookahead, shard_hb in ((0, 0), (1, 0), (1, 1)):
+        mgpu.set_option('lookahead', lookahead)
+        mgpu.set_option('shard_hb', shard_hb)
+        T = ctx.array(Theta)
+        assert mgpu.potrf(T.ptr, N, T.ld) == 0
+        got = np.tril(T.download())
+        assert np.max(np.abs(got - Lref)) <= 1e-9 * np.max(np.abs(Lref)), ('panel-sharded Cholesky', lookahead)
+        prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0, dinv=256)
+        S, H, delta, _ = prob.workspace()
+        S2 = ctx.empty(S.rows, S.cols, S.ld); S2.zero()
+        z = ctx.array(z0)
+        hist = []
+        for _ in range(3):
+            loss, info = mgpu.gn_step(prob.struct, z.ptr, 1.0, S.ptr, S.ld, S2.ptr, H.ptr, H.ld, delta.ptr)
+            assert info == 0
+            hist.append(loss)
+        np.testing.assert_allclose(hist, hist_ref[:3], rtol=1e-6)
+        zz = z.download()
+        assert np.linalg.norm(zz - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref), (lookahead, shard_hb)
+        results.append(zz)
+        prob.release_workspace()
+    # a non-positive pivot in a panel of rank 1: every rank reports the same LAPACK index
+    bad = Theta.copy(); bad[200, 200] = -1.0
+    T = ctx.array(bad)
+    assert mgpu.potrf(T.ptr, N, T.ld) == 201
+    np.save(os.path.join({out!r}, f'z_{{rank}}.npy'), np.stack(results))
+    dist.barrier()
+    mgpu.close()
+    dist.destroy_process_group()
+    ctx.close()
+    print('rank', rank, 'ok')
+''')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_native_schedule_several_ranks_one_gpu(world, tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-3000:] for o in outs]
+    assert all('ok' in o[0] for o in outs)
+    zs = [np.load(tmp_path / f'z_{r}.npy') for r in range(world)]
+    for z in zs[1:]:
+        assert np.array_equal(z, zs[0])                               # replicated iterate, bit for bit, in every mode
