@@ -51,6 +51,9 @@ struct gpk_ctx {
     size_t splitk_ws_cap = 0;       // bytes
     unsigned* d_splitk_cnt = nullptr;
     int splitk_cnt_cap = 0;         // counters
+    void* sk_cache = nullptr;       // tile-list ("stream-K") plans of the GEMM launches, by launch shape (gpk_gemm.hip)
+    int no_sk = 0;                  // != 0: the NEXT gpk_i_gemm calls must not use tile lists (their partial-sum workspace and counters are
+                                    // the split-K ones: one stream of a handle at a time -- set around launches on secondary streams)
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
@@ -104,6 +107,7 @@ int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv
 int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int db, int n, int ldl, double* B, int ldb,
                          double* X, int ldx, int nrhs, int lead, int row0);
 int gpk_i_pipe_streams(gpk_handle h);                                                   // the two CU-masked streams of the pipeline (gpk_factor.hip); called by gpk_create
+void gpk_i_sk_free(gpk_handle h);                                                      // tile-list plans (gpk_gemm.hip)
 int gpk_i_splitk_reserve(gpk_handle h);                                                 // workspace + counters of the split-K launches
 int gpk_i_workspace(gpk_handle h, size_t bytes, double** out);                          // handle-owned scratch, grown on demand
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx);

@@ -61,6 +61,7 @@ extern "C" int gpk_destroy(gpk_handle h) {
     if (h->d_obflags) (void)hipFree(h->d_obflags);
     if (h->d_pts) (void)hipFree(h->d_pts);
     if (h->d_work) (void)hipFree(h->d_work);
+    gpk_i_sk_free(h);
     if (h->d_splitk_ws) (void)hipFree(h->d_splitk_ws);
     if (h->d_splitk_cnt) (void)hipFree(h->d_splitk_cnt);
     for (hipEvent_t e : h->pipe_ev) (void)hipEventDestroy(e);

@@ -2029,7 +2029,7 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
     hipEvent_t* ev_pre = h->pipe_ev.data() + 3 * J + 1;              // [J] (lookahead only)
     int rc = 0, ntev = 0;
     auto fail = [&](hipError_t e, const char* what) {               // restore the handle's stream and drain both side streams before reporting
-        h->stream = main_s;
+        h->stream = main_s; h->no_sk = 0;
         (void)hipStreamSynchronize(G); (void)hipStreamSynchronize(C);
         return gpk_fail(h, e, what, __FILE__, __LINE__);
     };
@@ -2107,13 +2107,16 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
             if (rc) break;
         }
         h->stream = C;
+        h->no_sk = 1;                                                // (the tile-list workspace belongs to the GEMM stream while both run)
         PIPE_HIP(hipStreamWaitEvent(C, ev_ready[j], 0));
         rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, pivot_base + j0, g_left_looking_panels != 0,
                                (g_pipeline_lookahead && j > 0) ? ev_ready2[j] : nullptr, (g_pipeline_lookahead && j + 1 < J && ob > NB) ? ev_pre[j] : nullptr);
+        h->no_sk = 0;
         if (rc) break;
         PIPE_HIP(hipEventRecord(ev_chain[j], C));
     }
     h->stream = main_s;
+    h->no_sk = 0;
     if (rc) {                                                        // drain both side streams before reporting
         (void)hipStreamSynchronize(G); (void)hipStreamSynchronize(C);
         return rc;

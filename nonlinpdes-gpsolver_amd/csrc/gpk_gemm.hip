@@ -24,12 +24,22 @@
 // 8 contiguous chunks (one per XCD L2), ordered in groups of 8 tile rows so that a chunk re-uses its A/B panels.
 #include "gpk_common.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
+
+struct SkSeg {
+    int tm, tn;        // tile (a triangular-operand launch lists single row tiles, not pairs)
+    int kbeg, kend;    // slabs
+    int part, nparts;  // nparts == 1: the whole tile (direct epilogue); else partial `part` of `nparts` (K order)
+    int slot0;         // first workspace slot (BM * BN doubles each) of the tile's partials
+    int ticket;        // arrival counter of the tile
+};
 
 struct GemmArgs {
     int M, N, K;
@@ -61,13 +71,19 @@ struct GemmArgs {
                        // long K loop (the 512-column products of the pipelined phase: one wave of 100-900 tiles with K up to 8400)
     double* ws;        // splitk: ntiles * splitk * BM * BN doubles
     unsigned* cnt;     // splitk: one arrival counter per tile, zero before the launch, reset to zero by the last arriver
+    // Tile-list ("stream-K") launches: the host cuts the launch's slab iterations -- all tiles in the launch's order, each with ITS
+    // K range (leading zeros, triangular operand) -- into equal shares, one per RESIDENT workgroup slot, and hands every workgroup its
+    // list of segments.  A tile cut between workgroups is finished by the last arriver exactly like a split-K tile (partials in
+    // `ws`, K order).  No tail of half-empty rounds, no long-tile / short-tile imbalance; the grid is one workgroup per slot.
+    const SkSeg* sk_segs;
+    const int* sk_off; // segments of block b: [sk_off[b], sk_off[b + 1])
 };
+
 
 // KC = true : operand stored [x][k] (k contiguous);  KC = false : stored [k][x] (x contiguous)
 template <bool KC, int BX, int NT = 256>
 __device__ __forceinline__ void load_tile(const double* __restrict__ P, long ld, int x0, int X, int k0, int K, bool vec,
-                                          d2 (&r)[BX * BK / (2 * NT)]) {
-    const int t = threadIdx.x;
+                                          d2 (&r)[BX * BK / (2 * NT)], const int t) {
     // interior tiles (workgroup-uniform test -> scalar branch): unguarded 16-byte loads
     if (vec && x0 + BX <= X && k0 + BK <= K) {
 #pragma unroll
@@ -98,8 +114,7 @@ __device__ __forceinline__ void load_tile(const double* __restrict__ P, long ld,
 }
 
 template <bool KC, int BX, int NT = 256>
-__device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&r)[BX * BK / (2 * NT)]) {
-    const int t = threadIdx.x;
+__device__ __forceinline__ void store_tile(double* __restrict__ lds, const d2 (&r)[BX * BK / (2 * NT)], const int t) {
 #pragma unroll
     for (int i = 0; i < BX * BK / (2 * NT); ++i) {
         const int lin = t + NT * i;
@@ -228,8 +243,8 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
     return true;
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool TRI = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) >= 16 ? 1 : 2)) void gemm_f64_kernel(GemmArgs g) {
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, bool TRI = false, bool SK = false>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) >= 16 ? 1 : 2)) void gemm_f64_kernel(GemmArgs gk) {
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int NT = (BM / WM) * (BN / WN) * 64;                   // threads: 4 waves, or 8 for the 128 x 64 tile
     constexpr bool PF2 = (BM * BN <= 64 * 64) || NT >= 512;                     // prefetch depth 2 for the small-tile configuration
@@ -241,21 +256,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     double* const As = smem;
     double* const Bs = smem + 2 * A_SZ;
 
-    const int nsplit = g.splitk;
-    const int bt = nsplit > 1 ? (int)blockIdx.x / nsplit : (int)blockIdx.x;
-    const int chunk = nsplit > 1 ? (int)blockIdx.x - bt * nsplit : 0;
-    int tm_map, tn;
-    if (!map_tile(g, bt, tm_map, tn)) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
-    const int li = lane & 15, lk = lane >> 4;
-    const int n0 = tn * BN;
+    const int nsplit_launch = SK ? 1 : gk.splitk;
+    const int bt = nsplit_launch > 1 ? (int)blockIdx.x / nsplit_launch : (int)blockIdx.x;
+    const int chunk_launch = nsplit_launch > 1 ? (int)blockIdx.x - bt * nsplit_launch : 0;
+    int tm_map = 0, tn_map = 0;
+    if (!SK && !map_tile(gk, bt, tm_map, tn_map)) return;
     // Lower-triangular A (tri_a): the K loop of row tile t ends at (t+1) BM, so tile t costs ~(t+1) units.  The grid then has
     // one workgroup per PAIR of row tiles (t, ntm_full-1-t) -- constant work per workgroup whatever the dispatcher does (with
     // one tile per workgroup, the four tiles a CU received had the same t: 4..64 slabs against an average of 34).
     // (TRI is a template parameter and the tile body a lambda: as a runtime loop around the body it cost every instantiation
     // 30-50 VGPRs and a wave of occupancy)
-    if (g.stagger > 0) {
+    if (!SK && gk.stagger > 0) {
         // EXPERIMENT (gpk_debug_set key 15, off by default): de-phase the workgroups that share a CU.  A one-wave launch with a
         // long K loop (1008 tiles, K = 4352) runs in lock-step -- the four workgroups of a CU load, wait at their barrier and
         // compute at the same moments -- and reaches 56-59 TFLOP/s; with a start-time stagger of slot x 1024 cycles it reaches
@@ -264,11 +275,24 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         // and neither do the one-wave, long-K product launches of the pipelined phase (sum of launches 2.70-2.74 ms either way), so it
         // stays off.  The wave slot id (HW_REG_HW_ID[3:0]) differs between the co-resident workgroups.
         const int slot = __builtin_amdgcn_s_getreg((4 << 11) | 4) & 0xf;    // size 4, offset 0, register 4 (HW_ID)
-        for (int i = 0; i < (slot & 3) * g.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+        for (int i = 0; i < (slot & 3) * gk.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     }
-    auto tile = [&](const int tm) __attribute__((always_inline)) {
+    // sk_*: the segment of a tile-list launch (SK); otherwise the K range follows from the launch parameters
+    // (tile-list launches call this in a loop: the launch arguments arrive as a per-iteration copy and the thread index through an
+    // opaque move, so that nothing the body derives from them is kept in registers across the whole K loop of the NEXT segment --
+    // hoisted, they cost every instantiation 20-36 VGPRs and a wave of occupancy)
+    auto tile = [&](const GemmArgs& g, const int tm, const int tn, const int sk_kbeg, const int sk_kend, const int sk_part, const int sk_nparts,
+                    const int sk_slot0, const int sk_ticket) __attribute__((always_inline)) {
+    int tix = threadIdx.x;
+    if (SK) asm volatile("" : "+v"(tix));
+    const int lane = tix & 63, wave = tix >> 6;
+    const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+    const int li = lane & 15, lk = lane >> 4;
     const int m0 = tm * BM;
-    if (g.skip_upper && m0 + BM <= n0) return;
+    const int n0 = tn * BN;
+    if (!SK && g.skip_upper && m0 + BM <= n0) return;
+    const int nsplit = SK ? sk_nparts : nsplit_launch;
+    const int chunk = SK ? sk_part : chunk_launch;
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -288,7 +312,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         if (kt0 > nk) kt0 = nk;
     }
     int kbeg = kt0, kend = nk;                                       // this workgroup's slabs
-    if (nsplit > 1) {
+    if (SK) {
+        kbeg = sk_kbeg; kend = sk_kend;
+    } else if (nsplit > 1) {
         const int len = (nk - kt0 + nsplit - 1) / nsplit;
         kbeg = min(kt0 + chunk * len, nk);
         kend = min(kbeg + len, nk);
@@ -324,7 +350,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         const bool fast = g.vecA && g.vecB;
         const int nkf = fast ? min(Kt / BK, kend) : kbeg;             // full slabs
         if (nkf > kbeg) {
-            const int t = threadIdx.x;
+            const int t = tix;
             const double* pa[NA]; const double* pb[NB];
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
@@ -349,8 +375,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
                 for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const d2*>(pb[i] + kc * sb);
             };
             auto store = [&](int buf, const d2 (&ra)[NA], const d2 (&rb)[NB]) {
-                store_tile<!TA, BM, NT>(As + buf * A_SZ, ra);
-                store_tile<TB, BN, NT>(Bs + buf * B_SZ, rb);
+                store_tile<!TA, BM, NT>(As + buf * A_SZ, ra, tix);
+                store_tile<TB, BN, NT>(Bs + buf * B_SZ, rb, tix);
             };
             load(kbeg, ra0, rb0);
             load(kbeg + 1, ra1, rb1);
@@ -372,21 +398,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     }
     if (kdone < kend) {                                               // edge tiles, unaligned operands, the partial slab
         d2 ra[NA], rb[NB];
-        load_tile<!TA, BM, NT>(g.A, g.lda, m0, g.M, kdone * BK, Kt, g.vecA, ra);
-        load_tile<TB, BN, NT>(g.B, g.ldb, n0, g.N, kdone * BK, Kt, g.vecB, rb);
-        store_tile<!TA, BM, NT>(As + (kdone & 1) * A_SZ, ra);
-        store_tile<TB, BN, NT>(Bs + (kdone & 1) * B_SZ, rb);
+        load_tile<!TA, BM, NT>(g.A, g.lda, m0, g.M, kdone * BK, Kt, g.vecA, ra, tix);
+        load_tile<TB, BN, NT>(g.B, g.ldb, n0, g.N, kdone * BK, Kt, g.vecB, rb, tix);
+        store_tile<!TA, BM, NT>(As + (kdone & 1) * A_SZ, ra, tix);
+        store_tile<TB, BN, NT>(Bs + (kdone & 1) * B_SZ, rb, tix);
         __syncthreads();
         for (int kt = kdone; kt < kend; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < kend) {
-                load_tile<!TA, BM, NT>(g.A, g.lda, m0, g.M, (kt + 1) * BK, Kt, g.vecA, ra);
-                load_tile<TB, BN, NT>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, Kt, g.vecB, rb);
+                load_tile<!TA, BM, NT>(g.A, g.lda, m0, g.M, (kt + 1) * BK, Kt, g.vecA, ra, tix);
+                load_tile<TB, BN, NT>(g.B, g.ldb, n0, g.N, (kt + 1) * BK, Kt, g.vecB, rb, tix);
             }
             compute(cur);
             if (kt + 1 < kend) {
-                store_tile<!TA, BM, NT>(As + (cur ^ 1) * A_SZ, ra);
-                store_tile<TB, BN, NT>(Bs + (cur ^ 1) * B_SZ, rb);
+                store_tile<!TA, BM, NT>(As + (cur ^ 1) * A_SZ, ra, tix);
+                store_tile<TB, BN, NT>(Bs + (cur ^ 1) * B_SZ, rb, tix);
             }
             __syncthreads();
         }
@@ -396,15 +422,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         // Hand-over across workgroups (other CUs, other XCDs: private L1s, non-coherent L2s): the accumulators leave as
         // write-through (agent-scope, sc1) stores, every wave waits for the acknowledgements of its own, then one lane takes the
         // ticket; the last arriver reads the chunks with sc1 loads (MI355X_MICROARCH.md, "splitk-seam").
-        const long tid = (long)tm * g.ntn + tn;
-        double* const wt = g.ws + tid * nsplit * (BM * BN);
+        const long tid = SK ? (long)sk_ticket : (long)tm * g.ntn + tn;
+        double* const wt = g.ws + (SK ? (long)sk_slot0 : tid * nsplit) * (BM * BN);
         double* const mine = wt + (long)chunk * (BM * BN);
         // (16-byte write-through stores: two per accumulator tile and lane; as 8-byte agent-scope atomics they cost 2.7x per byte)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                double* dst = mine + ((i * TN + j) * NT + (int)threadIdx.x) * 4;
+                double* dst = mine + ((i * TN + j) * NT + tix) * 4;
                 const d2 lo = (d2){acc[i][j][0], acc[i][j][1]}, hi = (d2){acc[i][j][2], acc[i][j][3]};
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" :: "v"(dst), "v"(lo), "v"(hi) : "memory");
             }
@@ -413,11 +439,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         // (the ticket travels through the first word of the operand buffers, which nobody reads any more: a variable of its own
         // would cost the 64x64 TN instantiation its fourth workgroup per CU -- 4 x 40 KB are exactly the 160 KB of LDS)
         unsigned* const s_ticket = reinterpret_cast<unsigned*>(smem);
-        if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(g.cnt + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tix == 0) *s_ticket = __hip_atomic_fetch_add(g.cnt + tid, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned ticket = *s_ticket;
+        if (SK) __syncthreads();                                      // (the next segment's first slab overwrites the ticket word)
         if (ticket != (unsigned)(nsplit - 1)) return;
-        if (threadIdx.x == 0) __hip_atomic_store(g.cnt + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        if (tix == 0) __hip_atomic_store(g.cnt + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         d4 sum[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -433,7 +460,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        sum[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * NT + (int)threadIdx.x) * 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sum[i][j][r] += __hip_atomic_load(src + ((i * TN + j) * NT + tix) * 4 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -460,12 +487,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         }
     }
     };
-    if (TRI) {
-        const int hi = g.ntm_full - 1 - tm_map;                       // the long tile first
-        tile(hi);
-        if (hi != tm_map) tile(tm_map);                               // odd count: the middle tile is its own partner
+    if (SK) {
+        const int s0 = gk.sk_off[blockIdx.x], s1 = gk.sk_off[blockIdx.x + 1];
+        for (int si = s0; si < s1; ++si) {
+            // the launch arguments re-read from the kernarg segment behind an opaque move of its address (scalar loads, a few dozen
+            // dwords per segment): as loop invariants they would occupy ~40 SGPRs for the whole kernel and spill into VGPR lanes
+            typedef const __attribute__((address_space(4))) GemmArgs* karg_ptr;
+            karg_ptr gp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(gp));
+            GemmArgs g;
+#define GPK_CP(f) g.f = gp->f;
+            GPK_CP(M) GPK_CP(N) GPK_CP(K) GPK_CP(alpha) GPK_CP(beta) GPK_CP(A) GPK_CP(lda) GPK_CP(B) GPK_CP(ldb) GPK_CP(C) GPK_CP(ldc)
+            GPK_CP(lower_only) GPK_CP(lead_div) GPK_CP(lead) GPK_CP(skip_upper) GPK_CP(stagger) GPK_CP(rev_k) GPK_CP(tri_a) GPK_CP(vecA) GPK_CP(vecB)
+            GPK_CP(ntm) GPK_CP(ntn) GPK_CP(ntiles) GPK_CP(ntm_full) GPK_CP(band) GPK_CP(nsuper) GPK_CP(splitk) GPK_CP(ws) GPK_CP(cnt)
+            GPK_CP(sk_segs) GPK_CP(sk_off)
+#undef GPK_CP
+            // (wave-uniform by construction: through SGPRs, so that the loop costs no vector registers)
+            const int* q = reinterpret_cast<const int*>(g.sk_segs + si);
+            const int a0 = __builtin_amdgcn_readfirstlane(q[0]), a1 = __builtin_amdgcn_readfirstlane(q[1]);
+            const int a2 = __builtin_amdgcn_readfirstlane(q[2]), a3 = __builtin_amdgcn_readfirstlane(q[3]);
+            const int a4 = __builtin_amdgcn_readfirstlane(q[4]), a5 = __builtin_amdgcn_readfirstlane(q[5]);
+            const int a6 = __builtin_amdgcn_readfirstlane(q[6]), a7 = __builtin_amdgcn_readfirstlane(q[7]);
+            tile(g, a0, a1, a2, a3, a4, a5, a6, a7);
+        }
+    } else if (TRI) {
+        const int hi = gk.ntm_full - 1 - tm_map;                       // the long tile first
+        tile(gk, hi, tn_map, 0, 0, 0, 1, 0, 0);
+        if (hi != tm_map) tile(gk, tm_map, tn_map, 0, 0, 0, 1, 0, 0);     // odd count: the middle tile is its own partner
     } else {
-        tile(tm_map);
+        tile(gk, tm_map, tn_map, 0, 0, 0, 1, 0, 0);
     }
 }
 
@@ -493,8 +543,8 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
     d2 ra[NK][BM * BK / 512], rb[NK][BN * BK / 512];
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
-        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kt * BK, g.K, g.vecA, ra[kt]);
-        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kt * BK, g.K, g.vecB, rb[kt]);
+        load_tile<!TA, BM>(g.A, g.lda, m0, g.M, kt * BK, g.K, g.vecA, ra[kt], (int)threadIdx.x);
+        load_tile<TB, BN>(g.B, g.ldb, n0, g.N, kt * BK, g.K, g.vecB, rb[kt], (int)threadIdx.x);
     }
     // accumulators start from C (sign folded in: the only combinations routed here are beta = 0, or beta = 1 with
     // alpha = +-1, for which acc = C/alpha is exact)
@@ -513,8 +563,8 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
             }
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
-        store_tile<!TA, BM>(As + kt * A_SZ, ra[kt]);
-        store_tile<TB, BN>(Bs + kt * B_SZ, rb[kt]);
+        store_tile<!TA, BM>(As + kt * A_SZ, ra[kt], (int)threadIdx.x);
+        store_tile<TB, BN>(Bs + kt * B_SZ, rb[kt], (int)threadIdx.x);
     }
     __syncthreads();
 #pragma unroll
@@ -573,6 +623,207 @@ int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     return launch_k64_bm<64>(h, ta, tb, g);
 }
 
+
+// ---- tile-list ("stream-K") plans: built on the host per launch SHAPE, cached on the device ------------------------------------
+int g_sk = 1;                                                        // gpk_debug_set key 42: 0 = never, 1 = automatic, 2 = every eligible launch
+int g_sk_rounds = 6;                                                 // gpk_debug_set key 43: automatic mode uses tile lists for launches of fewer than this many rounds of resident workgroups
+int g_sk_snap = 4;                                                   // gpk_debug_set key 44: a share boundary closer than this many slabs to a tile boundary moves there
+
+struct SkKey {
+    int bm, bn, M, N, K, lower, lead, lead_div, tri, skip_upper, band, G;
+    bool operator==(const SkKey& o) const { return memcmp(this, &o, sizeof(SkKey)) == 0; }
+};
+struct SkPlan {
+    SkKey key;
+    std::vector<SkSeg> segs;                                         // (host copies stay alive: the upload may read them late)
+    std::vector<int> off;
+    SkSeg* d_segs = nullptr;
+    int* d_off = nullptr;
+    int nblocks = 0, nslots = 0, ntickets = 0;
+    unsigned long stamp = 0;
+};
+struct SkCache {
+    std::vector<SkPlan*> plans;
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    unsigned long clock = 0;
+};
+
+// the tiles of a launch in the order the one-tile-per-workgroup kernel would take them (see map_tile), with their slab ranges
+struct SkTile { int tm, tn, k0, k1; };
+template <int BM, int BN>
+void sk_enumerate(const GemmArgs& g, std::vector<SkTile>& out) {
+    out.clear();
+    const int T = g.tri_a ? g.ntm_full : g.ntm;                      // row tiles
+    auto push = [&](int tm, int tn) {
+        const int m0 = tm * BM, n0 = tn * BN;
+        if (g.skip_upper && m0 + BM <= n0) return;
+        const int Kt = g.tri_a ? std::min(g.K, m0 + BM) : g.K;
+        const int nk = (Kt + BK - 1) / BK;
+        int kt0 = 0;
+        if (g.lead > 0) {
+            const int z = g.lead - (n0 + BN);
+            kt0 = z > 0 ? (z / g.lead_div) / BK : 0;
+            if (kt0 > nk) kt0 = nk;
+        }
+        out.push_back({tm, tn, kt0, nk});
+    };
+    if (g.lower_only) {
+        if (g.lead > 0 && g.band > 0) {
+            for (int r1 = T; r1 > 0;) {                               // bands of tile rows from the bottom
+                const int r0 = std::max(r1 - g.band, 0), rows = r1 - r0;
+                for (int c = 0; c < rows; ++c) for (int tm = r1 - 1 - c; tm < r1; ++tm) push(tm, r1 - 1 - c);
+                for (int tn = r0 - 1; tn >= 0; --tn) for (int tm = r0; tm < r1; ++tm) push(tm, tn);
+                r1 = r0;
+            }
+        } else if (g.lead > 0) {
+            for (int tn = T - 1; tn >= 0; --tn) for (int tm = tn; tm < T; ++tm) push(tm, tn);
+        } else {
+            for (int tm = 0; tm < T; ++tm) for (int tn = 0; tn <= tm; ++tn) push(tm, tn);
+        }
+        return;
+    }
+    auto rows_of = [&](int r0, int r1, int tn) {                      // row tiles [r0, r1) of one column; triangular operand: long tiles first
+        if (g.tri_a) { for (int tm = r1 - 1; tm >= r0; --tm) push(tm, tn); }
+        else         { for (int tm = r0; tm < r1; ++tm) push(tm, tn); }
+    };
+    if (g.lead > 0) {
+        const int band = (g.band > 0 && !g.tri_a) ? g.band : T;
+        for (int r0 = 0; r0 < T; r0 += band)
+            for (int tn = g.ntn - 1; tn >= 0; --tn) rows_of(r0, std::min(r0 + band, T), tn);
+    } else {
+        for (int r0 = 0; r0 < T; r0 += 8)
+            for (int tn = 0; tn < g.ntn; ++tn) rows_of(r0, std::min(r0 + 8, T), tn);
+    }
+}
+
+template <int BM, int BN>
+SkPlan* sk_build(const GemmArgs& g, int G, const SkKey& key) {
+    std::vector<SkTile> tiles;
+    sk_enumerate<BM, BN>(g, tiles);
+    long total = 0;
+    for (const SkTile& t : tiles) total += t.k1 - t.k0;
+    if (tiles.empty() || total <= 0) return nullptr;
+    SkPlan* p = new SkPlan();
+    p->key = key;
+    G = (int)std::min<long>(G, std::max<long>(1, total / 8));        // at least 8 slabs per workgroup
+    G = std::max(8, (G / 8) * 8);
+    // share boundaries in units of slabs over the concatenated tiles, snapped to nearby tile boundaries
+    std::vector<long> pre(tiles.size() + 1, 0);
+    for (size_t i = 0; i < tiles.size(); ++i) pre[i + 1] = pre[i] + (tiles[i].k1 - tiles[i].k0);
+    std::vector<long> bnd((size_t)G + 1);
+    size_t ti = 0;
+    for (int w = 0; w <= G; ++w) {
+        long b = (long)((double)total * w / G + 0.5);
+        if (w == 0) b = 0;
+        if (w == G) b = total;
+        while (ti + 1 < pre.size() && pre[ti + 1] <= b) ++ti;        // pre[ti] <= b < pre[ti + 1] (or the end)
+        if (b - pre[ti] < g_sk_snap) b = pre[ti];
+        else if (ti + 1 < pre.size() && pre[ti + 1] - b < g_sk_snap) b = pre[ti + 1];
+        if (w > 0 && b < bnd[w - 1]) b = bnd[w - 1];
+        bnd[w] = b;
+    }
+    // parts per tile
+    std::vector<int> nparts(tiles.size(), 0), slot0(tiles.size(), 0), seen(tiles.size(), 0);
+    {
+        size_t t = 0;
+        for (int w = 0; w < G; ++w) {
+            long a = bnd[w];
+            const long e = bnd[w + 1];
+            while (a < e) {
+                while (pre[t + 1] <= a) ++t;
+                const long stop = std::min(e, pre[t + 1]);
+                nparts[t] += 1;
+                a = stop;
+            }
+        }
+    }
+    int slots = 0, tickets = 0;
+    std::vector<int> ticket(tiles.size(), 0);
+    for (size_t t = 0; t < tiles.size(); ++t) {
+        if (nparts[t] > 1) { slot0[t] = slots; slots += nparts[t]; ticket[t] = tickets++; }
+    }
+    // segments per share; zero-length tiles (all-zero K range) ride with the share that owns their position
+    std::vector<std::vector<SkSeg>> per((size_t)G);
+    {
+        size_t t = 0;
+        for (int w = 0; w < G; ++w) {
+            long a = bnd[w];
+            const long e = bnd[w + 1];
+            while (a < e) {
+                while (pre[t + 1] <= a) ++t;
+                const long stop = std::min(e, pre[t + 1]);
+                const SkTile& tl = tiles[t];
+                per[w].push_back({tl.tm, tl.tn, (int)(tl.k0 + (a - pre[t])), (int)(tl.k0 + (stop - pre[t])), seen[t], nparts[t], slot0[t], ticket[t]});
+                seen[t] += 1;
+                a = stop;
+            }
+        }
+        int w = 0;
+        for (size_t i = 0; i < tiles.size(); ++i) {
+            if (tiles[i].k1 > tiles[i].k0) continue;
+            while (w + 1 < G && bnd[w + 1] <= pre[i] && bnd[w + 1] < total) ++w;
+            per[w].push_back({tiles[i].tm, tiles[i].tn, tiles[i].k0, tiles[i].k0, 0, 1, 0, 0});
+        }
+    }
+    // hardware block b runs on XCD b % 8: consecutive shares go to ONE XCD (its L2 sees neighbouring tiles)
+    p->off.assign((size_t)G + 1, 0);
+    p->segs.clear();
+    const int per_xcd = G / 8;
+    for (int b = 0; b < G; ++b) {
+        const int w = (b % 8) * per_xcd + b / 8;
+        p->off[b] = (int)p->segs.size();
+        p->segs.insert(p->segs.end(), per[w].begin(), per[w].end());
+    }
+    p->off[G] = (int)p->segs.size();
+    p->nblocks = G; p->nslots = slots; p->ntickets = tickets;
+    return p;
+}
+
+int sk_upload(gpk_handle h, SkCache* c, SkPlan* p) {
+    const size_t need = ((p->segs.size() * sizeof(SkSeg) + 255) & ~(size_t)255) + ((p->off.size() * sizeof(int) + 255) & ~(size_t)255);
+    if (!c->arena) {
+        c->arena_cap = (size_t)48 << 20;
+        GPK_HIP(h, hipMalloc((void**)&c->arena, c->arena_cap));
+    }
+    if (c->arena_used + need > c->arena_cap) {                       // full: drop every plan (rare: hundreds of distinct launch shapes)
+        GPK_HIP(h, hipDeviceSynchronize());
+        for (SkPlan* q : c->plans) if (q != p) delete q;
+        c->plans.clear();
+        c->arena_used = 0;
+        if (need > c->arena_cap) return 1;
+    }
+    p->d_segs = (SkSeg*)(c->arena + c->arena_used);
+    p->d_off = (int*)(c->arena + c->arena_used + ((p->segs.size() * sizeof(SkSeg) + 255) & ~(size_t)255));
+    c->arena_used += need;
+    GPK_HIP(h, hipMemcpyAsync(p->d_segs, p->segs.data(), p->segs.size() * sizeof(SkSeg), hipMemcpyHostToDevice, h->stream));
+    GPK_HIP(h, hipMemcpyAsync(p->d_off, p->off.data(), p->off.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    // (tables are read by launches on other streams of this handle as well: make them visible to all of them)
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// plan for this launch, or nullptr when the launch should take the one-tile-per-workgroup path
+template <int BM, int BN>
+SkPlan* sk_plan_for(gpk_handle h, const GemmArgs& g, int G) {
+    if (!h->sk_cache) h->sk_cache = new SkCache();
+    SkCache* c = (SkCache*)h->sk_cache;
+    SkKey key;
+    memset(&key, 0, sizeof key);
+    key.bm = BM; key.bn = BN; key.M = g.M; key.N = g.N; key.K = g.K; key.lower = g.lower_only; key.lead = g.lead; key.lead_div = g.lead_div;
+    key.tri = g.tri_a; key.skip_upper = g.skip_upper; key.band = g.band; key.G = G;
+    for (SkPlan* p : c->plans) if (p->key == key) { p->stamp = ++c->clock; return p->nblocks > 0 ? p : nullptr; }
+    SkPlan* p = sk_build<BM, BN>(g, G, key);
+    if (!p) { p = new SkPlan(); p->key = key; }                       // remembered as "not worth it"
+    else if ((size_t)p->nslots * BM * BN * sizeof(double) > h->splitk_ws_cap || p->ntickets > h->splitk_cnt_cap || sk_upload(h, c, p) != 0) {
+        p->nblocks = 0;
+        (void)hipGetLastError();
+    }
+    p->stamp = ++c->clock;
+    c->plans.push_back(p);
+    return p->nblocks > 0 ? p : nullptr;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.ntm = gpk_ceil_div(g.M, BM);
@@ -616,6 +867,30 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     }
     dim3 grid(nblocks), block((BM / WM) * (BN / WN) * 64);
     const size_t dyn = (size_t)g_gemm_extra_lds;
+    g.sk_segs = nullptr; g.sk_off = nullptr;
+    // Tile-list launch?  Resident workgroup slots of this configuration (waves per workgroup -> workgroups per CU: 4 waves 4 (5 for the
+    // 32-row tile), 8 waves 2, 16 waves 1); worth it when the launch is only a few rounds of them -- then the last, partly filled
+    // round and the spread of tile lengths (leading zeros, triangular operand) cost a large share of its time.
+    if (g_sk && g.splitk == 1 && g.nsuper == 0 && !h->no_sk && !g.rev_k && g.K >= 4 * BK && h->num_cu >= 8) {
+        constexpr int WAVES = (BM / WM) * (BN / WN);
+        const int per_cu = WAVES >= 16 ? 1 : WAVES >= 8 ? 2 : (BM == 32 ? 5 : 4);
+        const int G = ((h->num_cu * per_cu) / 8) * 8;
+        const long eff = g.tri_a ? 2L * g.ntiles : (long)g.ntiles;
+        if ((g_sk == 2 || eff < (long)g_sk_rounds * G) && gpk_i_splitk_reserve(h) == 0) {
+            SkPlan* p = sk_plan_for<BM, BN>(h, g, G);
+            if (p) {
+                g.sk_segs = p->d_segs; g.sk_off = p->d_off; g.ws = h->d_splitk_ws; g.cnt = h->d_splitk_cnt;
+                dim3 sgrid(p->nblocks);
+                if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true, true><<<sgrid, block, dyn, h->stream>>>(g);
+                else if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false, false, true><<<sgrid, block, dyn, h->stream>>>(g);
+                else if (!ta && tb) gemm_f64_kernel<BM, BN, WM, WN, false, true, false, true><<<sgrid, block, dyn, h->stream>>>(g);
+                else if (ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, true, false, false, true><<<sgrid, block, dyn, h->stream>>>(g);
+                else gemm_f64_kernel<BM, BN, WM, WN, true, true, false, true><<<sgrid, block, dyn, h->stream>>>(g);
+                GPK_LAUNCH_CHECK(h);
+                return 0;
+            }
+        }
+    }
     if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true><<<grid, block, dyn, h->stream>>>(g);   // (only NN reaches here)
     else if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false><<<grid, block, dyn, h->stream>>>(g);
     else if (!ta && tb) gemm_f64_kernel<BM, BN, WM, WN, false, true><<<grid, block, dyn, h->stream>>>(g);
@@ -698,7 +973,19 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 35) { g_band_mb = value; return 0; }
     if (key == 38) { g_big_min = value; return 0; }
     if (key == 36) { g_syrk_band = value; return 0; }
+    if (key == 42) { g_sk = value; return 0; }
+    if (key == 43) { g_sk_rounds = value; return 0; }
+    if (key == 44) { g_sk_snap = value; return 0; }
     return GPK_ERR_ARG;
+}
+
+void gpk_i_sk_free(gpk_handle h) {
+    SkCache* c = (SkCache*)h->sk_cache;
+    if (!c) return;
+    for (SkPlan* p : c->plans) delete p;
+    if (c->arena) (void)hipFree(c->arena);
+    delete c;
+    h->sk_cache = nullptr;
 }
 
 int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha, const double* A, int lda,
@@ -716,6 +1003,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.stagger = g_stagger;
     g.band = 0; g.splitk = 1; g.ws = nullptr; g.cnt = nullptr; g.nsuper = 0; g.ntm_full = 0;   // (set per launch configuration below)
+    g.sk_segs = nullptr; g.sk_off = nullptr;
     g.rev_k = (g_rev_k && g.lead > 0) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);

@@ -219,6 +219,7 @@ int exec_potrf(gpk_mg_handle mg, double* A, int n, int lda) {
     for (const Op& op : plan) {
         const hipStream_t s = streams[op.stream];
         h->stream = s;
+        h->no_sk = (la && op.stream != 0) ? 1 : 0;                   // tile-list GEMM launches (one workspace per handle) only on the main stream
         const int k = (op.kind == GPK_MG_UPDATE) ? op.b : op.a;
         const int k0 = k * nb, kb = std::min(nb, n - k0);
         hipError_t e = hipSuccess;
@@ -253,6 +254,7 @@ int exec_potrf(gpk_mg_handle mg, double* A, int n, int lda) {
         if (rc) break;
     }
     h->stream = main_s;
+    h->no_sk = 0;
     if (rc && la) { (void)hipStreamSynchronize(mg->s_panel); (void)hipStreamSynchronize(mg->s_comm); }
     return rc;
 }
