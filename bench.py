@@ -527,7 +527,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
     mgpu = None
     if engine == 'native':
         from gpk.mg import MultiGpu
-        mgpu = MultiGpu(ctx, rank, world, panel=args.panel, comm='rccl' if world > 1 else None)
+        mgpu = MultiGpu(ctx, rank, world, panel=args.panel, comm=os.environ.get('GPK_BENCH_COMM', 'rccl') if world > 1 else None)   # ('staged': several ranks on ONE GPU, tools/bench_two_ranks_one_gpu.sh)
     Xd, Xb, f, g, z0 = synthetic_problem(Nd, Nb)                  # identical on every rank (seeded)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
     tXd, tXb, tf, tg, z = t(Xd), t(Xb), t(f), t(g), t(z0)
@@ -536,18 +536,48 @@ def run_sharded(args, workload, steps=None, warmup=None):
     kp = gpk.device.kernel_params('Gaussian', SIGMA)
     ratios = (C.c_double * 3)()
     nugget = 1e-13
-    while True:
+    mode_probe = {}
+
+    def set_mode(lookahead=None, shard_hb=None):
+        if lookahead is not None:
+            if mgpu:
+                mgpu.set_option('lookahead', int(lookahead))
+            solver.lookahead = bool(lookahead)
+        if shard_hb is not None:
+            if mgpu:
+                mgpu.set_option('shard_hb', int(shard_hb))
+            solver.shard_hb = bool(shard_hb)
+
+    def factor_once():
         # assembly shards trivially (every entry depends on two points); at 9.2 GB / 5 TB/s it is cheaper to let
         # every rank write the whole matrix than to communicate anything
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        torch.cuda.synchronize(); comm.barrier(); t0 = time.perf_counter()
         ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, tXd.data_ptr(), Nd, tXb.data_ptr(), Nb, nugget, 2, Theta.data_ptr(), ld, ratios))
-        torch.cuda.synchronize(); asm_ms = 1e3 * (time.perf_counter() - t0)
-        t0 = time.perf_counter()
-        info = mgpu.potrf(Theta.data_ptr(), N, ld) if mgpu else solver.potrf(Theta, N)
-        torch.cuda.synchronize(); chol_ms = 1e3 * (time.perf_counter() - t0)
+        torch.cuda.synchronize(); a_ms = 1e3 * (time.perf_counter() - t0)
+        comm.barrier(); t0 = time.perf_counter()
+        inf = mgpu.potrf(Theta.data_ptr(), N, ld) if mgpu else solver.potrf(Theta, N)
+        torch.cuda.synchronize(); c_ms = 1e3 * (time.perf_counter() - t0)
+        return a_ms, comm.max_float(c_ms, dev), inf
+
+    while True:
+        asm_ms, chol_ms, info = factor_once()
         if info == 0 or nugget >= 1e-8:
             break
         nugget *= 10.0
+    if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1':
+        # More than one rank: the factorisation is timed with BOTH plans -- look-ahead (default) and the strictly sequential
+        # factor -> broadcast -> update -- and the faster one (max over ranks, so every rank decides alike) is kept for what
+        # follows; both times are reported.  (Look-ahead hides broadcasts behind updates but its panel kernels share the CUs
+        # with the update GEMMs of the same GPU; which effect wins depends on the fabric.)
+        mode_probe['cholesky_theta_ms'] = {'lookahead': chol_ms}
+        set_mode(lookahead=0)
+        _, c2, info2 = factor_once()
+        mode_probe['cholesky_theta_ms']['sequential'] = c2
+        if c2 < chol_ms and info2 == info:
+            chol_ms = c2
+        else:
+            set_mode(lookahead=1)
+        mode_probe['lookahead_kept'] = bool(solver.lookahead)
     ps = GNProblemStruct()
     ps.system, ps.Nd, ps.Nb, ps.Ndata = 0, Nd, Nb, 0
     ps.p0, ps.p1, ps.pen_lambda = ALPHA, M_EXP, 0.0
@@ -569,8 +599,24 @@ def run_sharded(args, workload, steps=None, warmup=None):
     else:
         step = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
     losses = []
-    for _ in range(warmup):
-        losses.append(step())
+    if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1':
+        # the same for the Cholesky of the bordered Gauss-Newton matrix: one untimed-for-the-metric step each with the replicated
+        # and with the panel-sharded factorisation, the faster one kept (all ranks alike); these two steps count as warm-up
+        times = {}
+        for name, flag in (('replicated', 0), ('panel_sharded', 1)):
+            set_mode(shard_hb=flag)
+            comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+            losses.append(step())
+            torch.cuda.synchronize()
+            times[name] = comm.max_float(1e3 * (time.perf_counter() - t0), dev)
+        set_mode(shard_hb=int(times['panel_sharded'] < times['replicated']))
+        mode_probe['step_ms_by_cholesky_of_Hb'] = times
+        mode_probe['shard_hb_kept'] = bool(solver.shard_hb)
+        warmup_run = 2
+    else:
+        for _ in range(warmup):
+            losses.append(step())
+        warmup_run = warmup
     comm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -609,7 +655,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
         ex_rate = executed * steps / elapsed / 1e12
         out = {
             'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
-            'value': steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'value': steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup_run,
             'ms_per_step': 1e3 * elapsed / steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
@@ -620,10 +666,11 @@ def run_sharded(args, workload, steps=None, warmup=None):
                        'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step; only the factor of Theta and the inverses of its diagonal '
                                       'blocks are reused across steps); structural zeros of A(z) skipped as on one GPU, column shards cut by '
                                       'work; f1_tflops is the dense-equivalent rate, roofline.achieved the executed one'},
-            'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': warmup + steps,
+            'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': warmup_run + steps,
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
             'f1_tflops': rate,
             'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'diagonal_block_inverses': dinv_ms},
+            'mode_probe': mode_probe or None,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step: solve + product + Cholesky of Hb), flops EXECUTED summed over the ranks',
                          'achieved': ex_rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
                          'frac': ex_rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': None,
@@ -690,7 +737,7 @@ def main():
                 if out is not None and sh is not None:
                     out['sharded_config'] = {k: sh[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling',
                                                                  'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline',
-                                                                 'roofline_cholesky_theta') if k in sh}
+                                                                 'roofline_cholesky_theta', 'mode_probe') if k in sh}
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
                 msg = f'{type(e).__name__}: {e}'
                 if use_pg:

@@ -266,7 +266,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
     // one tile per workgroup, the four tiles a CU received had the same t: 4..64 slabs against an average of 34).
     // (TRI is a template parameter and the tile body a lambda: as a runtime loop around the body it cost every instantiation
     // 30-50 VGPRs and a wave of occupancy)
-    if (!SK && gk.stagger > 0) {
+    if (gk.stagger > 0) {
         // EXPERIMENT (gpk_debug_set key 15, off by default): de-phase the workgroups that share a CU.  A one-wave launch with a
         // long K loop (1008 tiles, K = 4352) runs in lock-step -- the four workgroups of a CU load, wait at their barrier and
         // compute at the same moments -- and reaches 56-59 TFLOP/s; with a start-time stagger of slot x 1024 cycles it reaches
@@ -627,6 +627,8 @@ int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
 // ---- tile-list ("stream-K") plans: built on the host per launch SHAPE, cached on the device ------------------------------------
 int g_sk = 1;                                                        // gpk_debug_set key 42: 0 = never, 1 = automatic, 2 = every eligible launch
 int g_sk_rounds = 6;                                                 // gpk_debug_set key 43: automatic mode uses tile lists for launches of fewer than this many rounds of resident workgroups
+int g_sk_stagger = 2;                                                // gpk_debug_set key 45: start stagger of the co-resident workgroups of a tile-list launch (slot x this x 512 cycles; every workgroup starts at once and has the same amount of work -- without it the four workgroups of a CU run in lock-step, see the kernel)
+int g_sk_rowclass = 1;                                               // gpk_debug_set key 46: 0 = keep the launch's tile order when cutting shares (experiment)
 int g_sk_snap = 4;                                                   // gpk_debug_set key 44: a share boundary closer than this many slabs to a tile boundary moves there
 
 struct SkKey {
@@ -701,6 +703,11 @@ template <int BM, int BN>
 SkPlan* sk_build(const GemmArgs& g, int G, const SkKey& key) {
     std::vector<SkTile> tiles;
     sk_enumerate<BM, BN>(g, tiles);
+    // Row tiles stay with "their" XCD, as in the one-tile-per-workgroup order (consecutive blocks = consecutive row tiles of a column,
+    // block b on XCD b % 8): the shares are handed to the XCDs in contiguous runs (below), so the tile sequence is regrouped by
+    // tm mod 8 first -- every XCD then works on 1/8 of the rows of A, which stay in ITS L2 while it sweeps the columns.  (Without
+    // this every XCD streamed all of A: the update launches of the solve phase ran 1.3 - 2.5x slower than one tile per workgroup.)
+    if (g_sk_rowclass) std::stable_sort(tiles.begin(), tiles.end(), [](const SkTile& a, const SkTile& b) { return (a.tm & 7) < (b.tm & 7); });
     long total = 0;
     for (const SkTile& t : tiles) total += t.k1 - t.k0;
     if (tiles.empty() || total <= 0) return nullptr;
@@ -876,10 +883,18 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         const int per_cu = WAVES >= 16 ? 1 : WAVES >= 8 ? 2 : (BM == 32 ? 5 : 4);
         const int G = ((h->num_cu * per_cu) / 8) * 8;
         const long eff = g.tri_a ? 2L * g.ntiles : (long)g.ntiles;
-        if ((g_sk == 2 || eff < (long)g_sk_rounds * G) && gpk_i_splitk_reserve(h) == 0) {
+        // Automatic mode: plain operands only.  Measured on the launches of the Gauss-Newton step (config 2, tools/sk_trace.sh): the
+        // leading-zero updates and the triangular products of the solve phase already run at 72-88 % of the clock-limited rate with
+        // one tile per workgroup (longest tile first; triangular tiles paired to constant work), and cutting their tiles costs more
+        // in partial sums than the balance returns (179 -> 250 us, 566 -> 643, 1255 -> 1208 for the three updates; 107-287 -> 119-339
+        // for the triangular products).  On plain products whose tile count is not a whole number of rounds the lists gain 12-21 %
+        // (tools/sk_probe.py: 1056 tiles 0.375 -> 0.329 ms, 2080 tiles 0.69 -> 0.61 ms), at whole rounds they are neutral.
+        const bool plain = g.lead == 0 && !g.tri_a && !g.lower_only && !g.skip_upper;
+        if ((g_sk == 2 || (plain && g.K >= 64 * BK && eff < (long)g_sk_rounds * G && eff % G > G / 16 && eff % G < G - G / 4)) && gpk_i_splitk_reserve(h) == 0) {
             SkPlan* p = sk_plan_for<BM, BN>(h, g, G);
             if (p) {
                 g.sk_segs = p->d_segs; g.sk_off = p->d_off; g.ws = h->d_splitk_ws; g.cnt = h->d_splitk_cnt;
+                if (g_sk_stagger > 0) g.stagger = g_sk_stagger;
                 dim3 sgrid(p->nblocks);
                 if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true, true><<<sgrid, block, dyn, h->stream>>>(g);
                 else if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false, false, true><<<sgrid, block, dyn, h->stream>>>(g);
@@ -976,6 +991,8 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 42) { g_sk = value; return 0; }
     if (key == 43) { g_sk_rounds = value; return 0; }
     if (key == 44) { g_sk_snap = value; return 0; }
+    if (key == 45) { g_sk_stagger = value; return 0; }
+    if (key == 46) { g_sk_rowclass = value; return 0; }
     return GPK_ERR_ARG;
 }
 
