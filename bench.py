@@ -283,6 +283,14 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
         if info == 0 or nugget >= 1e-8:
             break
         nugget *= 10.0                                            # SURVEY 7 hard part 1: report the nugget actually used
+    # the first factorisation of a process also pays the first launch of every kernel it uses (code-object load): time it once
+    # more on a freshly assembled matrix; both figures are reported, the roofline uses the second
+    chol_first_ms = chol_ms
+    ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, dXd.ptr, Nd, dXb.ptr, Nb, nugget, 2, T.ptr, T.ld, ratios))
+    ctx.timer_start()
+    info2 = ctx.potrf(T)
+    chol_ms = ctx.timer_stop()
+    assert info2 == info
     ctx.synchronize(); t0 = time.perf_counter()
     prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=ALPHA, p1=M_EXP)   # + gpk_trtri_diag of the factor (once per factor)
     ctx.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
@@ -360,7 +368,7 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
         'phases_ms_per_step': {'trsm': prof['trsm_ms'] / steps, 'syrk_and_potrf_H': phase_ms,
                                'syrk_launches_sum': syrk_ms, 'trsv_update': prof['trsv_update_ms'] / steps,
                                'pipelined': bool(pipelined), 'chain_partition_cus': prof['chain_cus'] if pipelined else 0},
-        'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms, 'diagonal_block_inverses': dinv_ms,
+        'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms, 'cholesky_theta_first_call': chol_first_ms, 'diagonal_block_inverses': dinv_ms,
                         'diagonal_block_rows': dinv_block},
         'roofline': ({'bound': 'mfma',
                       'kernel': 'gemm_f64_kernel<.., NN> = the solve phase S = L^{-1}[A | F]: update products of the recursion and '

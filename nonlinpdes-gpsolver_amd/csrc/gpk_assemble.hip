@@ -97,6 +97,57 @@ __device__ __forceinline__ void store_row(const AsmArgs& g, int p, int q, const 
     }
 }
 
+// Two column points per lane, one 16-byte store per (row functional, column functional, row point): a wave writes 1 KB contiguous
+// per store instruction and issues half as many of them.  Needs every block offset, the leading dimension and the base address to
+// be even multiples of 8 bytes (checked by the launcher; otherwise the one-point-per-lane kernel below runs).
+typedef double asm_d2 __attribute__((ext_vector_type(2)));
+
+template <int L, int BI, int BJ>
+__device__ __forceinline__ void store_block2(const AsmArgs& g, int p, int q, const double (&a0)[5], const double (&b0)[5], double e0,
+                                             const double (&a1)[5], const double (&b1)[5], double e1) {
+    if (q < g.size[BJ]) {                                            // (sizes are even here: q and q + 1 are both inside or both outside)
+        double v0 = pair_coeff<Lay<L>::f[BI], Lay<L>::f[BJ]>(a0, b0) * e0;
+        double v1 = pair_coeff<Lay<L>::f[BI], Lay<L>::f[BJ]>(a1, b1) * e1;
+        if (BI == BJ) { if (p == q) v0 += g.nug[BI]; if (p == q + 1) v1 += g.nug[BI]; }
+        *reinterpret_cast<asm_d2*>(g.out + (long)(g.off[BI] + p) * g.ld + g.off[BJ] + q) = (asm_d2){v0, v1};
+    }
+}
+
+template <int L, int BI>
+__device__ __forceinline__ void store_row2(const AsmArgs& g, int p, int q, const double (&a0)[5], const double (&b0)[5], double e0,
+                                           const double (&a1)[5], const double (&b1)[5], double e1) {
+    if (p < g.size[BI]) {                               // wave-uniform
+        store_block2<L, BI, 0>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 1) store_block2<L, BI, 1>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 2) store_block2<L, BI, 2>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 3) store_block2<L, BI, 3>(g, p, q, a0, b0, e0, a1, b1, e1);
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void assemble2_kernel(AsmArgs g) {
+    const int q = 2 * (blockIdx.x * 256 + threadIdx.x);
+    const bool live = q < g.M;                                       // (M even: q + 1 < M as well)
+    const double y1a = live ? g.px[q] : 0.0, y2a = live ? g.py[q] : 0.0;
+    const double y1b = live ? g.px[q + 1] : 0.0, y2b = live ? g.py[q + 1] : 0.0;
+    const int p0 = blockIdx.y * TP;
+    const int pend = min(p0 + TP, g.M);
+    for (int p = p0; p < pend; ++p) {
+        const double x1 = g.px[p], x2 = g.py[p];        // uniform address -> scalar loads
+        if (!live) continue;
+        const double d1a = x1 - y1a, d2a = x2 - y2a, d1b = x1 - y1b, d2b = x2 - y2b;
+        const double e0 = exp(-0.5 * (g.p1 * d1a * d1a + g.p2 * d2a * d2a));
+        const double e1 = exp(-0.5 * (g.p1 * d1b * d1b + g.p2 * d2b * d2b));
+        double a0[5], b0[5], a1[5], b1[5];
+        hermite(g.p1, d1a, a0); hermite(g.p2, d2a, b0);
+        hermite(g.p1, d1b, a1); hermite(g.p2, d2b, b1);
+        store_row2<L, 0>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 1) store_row2<L, 1>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 2) store_row2<L, 2>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 3) store_row2<L, 3>(g, p, q, a0, b0, e0, a1, b1, e1);
+    }
+}
+
 template <int L>
 __global__ __launch_bounds__(256) void assemble_kernel(AsmArgs g) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -222,6 +273,8 @@ template <int L> void diag_values(double p1, double p2, double (&c)[4]) {
 
 }  // namespace
 
+int g_asm_pairs = 1;                                                 // gpk_debug_set key 47: 0 = one column point per lane (8-byte stores) always
+
 extern "C" int gpk_assemble(gpk_handle h, int layout, int kernel, const double* kp, const double* Xd, int Nd,
                             const double* Xb, int Nb, double nugget, int nugget_type, double* Theta, int ld,
                             double* ratios) {
@@ -250,6 +303,20 @@ extern "C" int gpk_assemble(gpk_handle h, int layout, int kernel, const double* 
         else return gpk_bad_arg(h, "assemble: nugget_type");
     }
     g.out = Theta; g.ld = ld;
+    // two column points per lane (16-byte stores) when every pair (q, q + 1) stays inside one block and is 16-byte aligned
+    bool pairs = g_asm_pairs && (ld % 2 == 0) && (((uintptr_t)Theta & 15) == 0) && (g.M % 2 == 0);
+    for (int b = 0; b < nb; ++b) pairs = pairs && (g.off[b] % 2 == 0) && (g.size[b] % 2 == 0);
+    if (pairs) {
+        dim3 grid2(gpk_ceil_div(g.M / 2, 256), gpk_ceil_div(g.M, TP));
+        switch (layout) {
+            case GPK_LAYOUT_ELLIPTIC: assemble2_kernel<GPK_LAYOUT_ELLIPTIC><<<grid2, 256, 0, h->stream>>>(g); break;
+            case GPK_LAYOUT_BURGERS:  assemble2_kernel<GPK_LAYOUT_BURGERS><<<grid2, 256, 0, h->stream>>>(g); break;
+            case GPK_LAYOUT_EIKONAL:  assemble2_kernel<GPK_LAYOUT_EIKONAL><<<grid2, 256, 0, h->stream>>>(g); break;
+            case GPK_LAYOUT_DARCY_A:  assemble2_kernel<GPK_LAYOUT_DARCY_A><<<grid2, 256, 0, h->stream>>>(g); break;
+        }
+        GPK_LAUNCH_CHECK(h);
+        return 0;
+    }
     dim3 grid(gpk_ceil_div(g.M, 256), gpk_ceil_div(g.M, TP));
     switch (layout) {
         case GPK_LAYOUT_ELLIPTIC: assemble_kernel<GPK_LAYOUT_ELLIPTIC><<<grid, 256, 0, h->stream>>>(g); break;

@@ -993,6 +993,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 44) { g_sk_snap = value; return 0; }
     if (key == 45) { g_sk_stagger = value; return 0; }
     if (key == 46) { g_sk_rowclass = value; return 0; }
+    if (key == 47) { extern int g_asm_pairs; g_asm_pairs = value; return 0; }
     return GPK_ERR_ARG;
 }
 

@@ -484,3 +484,27 @@ def test_microbenchmarks_run(ctx):
     bw = ctx.ubench_hbm_write(1 << 28, 5)
     print(f'\n[ubench] v_mfma_f64_16x16x4_f64: {tf:.1f} TFLOP/s   streaming fp64 stores: {bw:.0f} GB/s')
     assert tf > 1.0 and bw > 100.0
+
+
+@pytest.mark.parametrize('layout,kernel,kp', [('Nonlinear_elliptic', 'Gaussian', 0.2), ('Burgers', 'anisotropic_Gaussian', [0.3, 0.05]),
+                                              ('Eikonal', 'Gaussian', 0.15), ('Darcy_a', 'Gaussian', 0.2)])
+def test_assembly_two_points_per_lane_is_bit_identical(ctx, layout, kernel, kp):
+    """gpk_assemble picks the kernel with two column points per lane (16-byte stores) when every block offset and size is even
+    (BASELINE configs 2, 4, 5); gpk_debug_set(47, 0) forces the one-point-per-lane kernel: same bits, and the oracle's values."""
+    rng = np.random.RandomState(17)
+    Nd, Nb = 310, 62
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    got = []
+    for pairs in (1, 0):
+        ctx.lib.gpk_debug_set(47, pairs)
+        try:
+            T, _ = ctx.assemble(layout, kernel, kp, Xd, Xb, 1e-6, 'adaptive')
+            got.append(T.download())
+        finally:
+            ctx.lib.gpk_debug_set(47, 1)
+    assert np.array_equal(got[0], got[1])
+    eqn = {'Darcy_a': 'Darcy_flow2d'}.get(layout, layout)
+    ref = O.gram_matrix_assembly(Xd, Xb, eqn, kernel, kp)
+    ref = ref[1] if layout == 'Darcy_a' else ref
+    want, _ = O.add_nugget(ref, layout, Nd, Nb, 1e-6)
+    assert np.max(np.abs(got[0] - want)) <= 4e-15 * np.max(np.abs(want))
