@@ -533,9 +533,21 @@ def run_sharded(args, workload, steps=None, warmup=None):
     # gpk/sharded.py over torch.distributed collectives (GPK_BENCH_SHARDED=python)
     engine = os.environ.get('GPK_BENCH_SHARDED', 'native')
     mgpu = None
+    engine_note = ''
     if engine == 'native':
         from gpk.mg import MultiGpu
-        mgpu = MultiGpu(ctx, rank, world, panel=args.panel, comm=os.environ.get('GPK_BENCH_COMM', 'rccl') if world > 1 else None)   # ('staged': several ranks on ONE GPU, tools/bench_two_ranks_one_gpu.sh)
+        err = ''
+        try:
+            mgpu = MultiGpu(ctx, rank, world, panel=args.panel, comm=os.environ.get('GPK_BENCH_COMM', 'rccl') if world > 1 else None)   # ('staged': several ranks on ONE GPU, tools/bench_two_ranks_one_gpu.sh)
+        except Exception as e:                                    # noqa: BLE001 -- e.g. the RCCL library cannot be bound: every rank must take the same branch
+            err = f'{type(e).__name__}: {e}'
+        if world > 1 and comm.max_int(1 if err else 0, dev):
+            if mgpu is not None:
+                mgpu.close()
+            mgpu = None
+            engine_note = f' (native executor unavailable on some rank{": " + err if err else ""}; fell back)'
+        elif err:
+            raise RuntimeError(err)
     Xd, Xb, f, g, z0 = synthetic_problem(Nd, Nb)                  # identical on every rank (seeded)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
     tXd, tXb, tf, tg, z = t(Xd), t(Xb), t(f), t(g), t(z0)
@@ -670,7 +682,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
                        'parallelism': solver.describe(world, gpk.device.dinv_block_for(N)),
                        'executor': (f'native: gpk_mg_potrf / gpk_mg_gn_step (C ABI), collectives = {getattr(mgpu, "comm_kind", "none (one rank)")}'
-                                    if mgpu else 'python: gpk/sharded.py over torch.distributed'),
+                                    if mgpu else 'python: gpk/sharded.py over torch.distributed' + engine_note),
                        'formulation': 'F1 (TRSM + SYRK + POTRF(H) + TRSV every step; only the factor of Theta and the inverses of its diagonal '
                                       'blocks are reused across steps); structural zeros of A(z) skipped as on one GPU, column shards cut by '
                                       'work; f1_tflops is the dense-equivalent rate, roofline.achieved the executed one'},
