@@ -18,6 +18,8 @@
 // True substitution everywhere except trsm_left_dinv.  The recursions split at multiples of 64/128/256 so that sub-blocks stay
 // 16-byte aligned for the GEMM's vector loads.
 #include "gpk_common.h"
+
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -502,10 +504,93 @@ __device__ __forceinline__ int panel_factor_lane_rows(double* __restrict__ Pc, i
     return bad;
 }
 
-template <int PW, bool UNROLLED>
+// FUSED (round 3): the kernel carries the rank-64 work that used to sit BETWEEN two panel kernels as launches of their own.
+//   * part B, at the start of the panel workgroups: the previous panel (the 64 columns to the left, `prevK` of them) is applied to
+//     this panel's columns of my rows while they are loaded -- accumulators -= L[my rows, prev] L[diagonal rows, prev]^T on the
+//     matrix cores, operands straight from global memory in fragment form (no LDS);
+//   * part A, in EXTRA workgroups behind the panel workgroups (which are dispatched first and all resident): a 64 x 64-tiled
+//     product C -= Aop Bop^T that does not depend on this panel and therefore runs NEXT TO its factorisation -- in the
+//     left-looking chain of the pipelined phase the contributions of the block's older panels to the NEXT panel's columns
+//     (K = 64 .. 384), in the right-looking factorisation the previous panel's rank-64 update of the block's remaining columns.
+// The chain per 64 columns becomes panel kernel (+ ~5 us of part B) instead of panel kernel + update launch (10 .. 42 us) + gap.
+struct PanelFuse {
+    int npanel;                     // workgroups of the panel part (1 + row blocks); blocks beyond run the product
+    int prevK;                      // part B: columns of the previous panel (0 or 64), stored directly left of A
+    double* gC; const double* gA; const double* gB;   // part A: C (gm x gn) -= gA (gm x gK) gB (gn x gK)^T, all with leading dimension lda
+    int gm, gn, gK, gtn;            // gtn = column tiles of C
+};
+
+typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+
+// extra workgroups of the fused panel kernel: one 64 x 64 tile of C -= A B^T, K a multiple of 16, operands in fragment form straight
+// from global memory (lane (li, lk) of a 16-row tile loads the 4 consecutive k's 4 lk .. 4 lk + 3 of row li: MFMA k-slot (step t, lane
+// group lk) then stands for k = 4 lk + t in BOTH operands, which is all a contraction needs), one 16-deep chunk prefetched ahead.
+// Meant for SHORT products (the rank-64 updates of the right-looking factorisation): fragment-shaped global loads keep the address
+// units busy twice as long as full-line loads staged through LDS, and with K = 64 .. 384 on the 32-CU chain partition this product
+// needed 48 - 96 us next to a 22 us panel (32 x 64 tiles, four chunks in flight: no better) -- see gpk_i_potrf_panel.
+constexpr int PFM = 64;                                              // tile rows of the fused product
+__device__ __forceinline__ void panel_fused_product(const PanelFuse& f, long lda, int tile) {
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    const int li = l & 15, lk = l >> 4;
+    const int tm = tile / f.gtn, tn = tile - tm * f.gtn;
+    const int m0 = tm * 64 + 32 * (w >> 1), n0 = tn * 64 + 32 * (w & 1);
+    const double* __restrict__ pa[2]; const double* __restrict__ pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        pa[i] = f.gA + (long)min(m0 + 16 * i + li, f.gm - 1) * lda + 4 * lk;
+        pb[i] = f.gB + (long)min(n0 + 16 * i + li, f.gn - 1) * lda + 4 * lk;
+    }
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    d4u a0[2], b0[2], a1[2], b1[2];
+    auto ld = [&](int kc, d4u (&a)[2], d4u (&b)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a[i] = *reinterpret_cast<const d4u*>(pa[i] + kc); b[i] = *reinterpret_cast<const d4u*>(pb[i] + kc); }
+    };
+    auto mm = [&](const d4u (&a)[2], const d4u (&b)[2]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    };
+    const int nch = f.gK / 16;
+    ld(0, a0, b0);
+    for (int c = 0; c < nch; c += 2) {
+        if (c + 1 < nch) ld(16 * (c + 1), a1, b1);
+        mm(a0, b0);
+        if (c + 1 >= nch) break;
+        if (c + 2 < nch) ld(16 * (c + 2), a0, b0);
+        mm(a1, b1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * i + lk + 4 * r;
+            if (row >= f.gm) continue;
+            double* __restrict__ crow = f.gC + (long)row * lda;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + 16 * j + li;
+                if (col < f.gn) crow[col] -= acc[i][j][r];
+            }
+        }
+}
+
+template <int PW, bool UNROLLED, bool FUSED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void potrf_panel_mfma_kernel(double* __restrict__ A, long lda, int nb, int below,
-                                                               int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
+                                                               int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg, PanelFuse fuse) {
     static_assert(PW == 8 || PW == 16, "panel width");
+    if (FUSED && (int)blockIdx.x >= fuse.npanel) {                   // part A: independent of this panel, next to its factorisation
+        panel_fused_product(fuse, lda, (int)blockIdx.x - fuse.npanel);
+        return;
+    }
+    const int ngrid = FUSED ? fuse.npanel : (int)gridDim.x;          // workgroups of the panel part
     constexpr int PSW = PW + 2;                                      // row stride of a panel buffer: 16-byte aligned rows, conflict-free b64 reads
     constexpr int KS = PW / 4;                                       // MFMA k-steps per panel
     constexpr int HPT = 16 / PW;                                     // panels per 16-column tile
@@ -516,7 +601,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int li = l & 15, lk = l >> 4;
     // (the LAST workgroup stores A_jj: it waits for tickets of workgroups with smaller indices only, which are dispatched first --
     // with workgroup 0 in that role a grid that is not fully resident can starve, see potrf_panel_la_kernel)
-    const bool tall = blockIdx.x + 1 < gridDim.x;
+    const bool tall = (int)blockIdx.x + 1 < ngrid;
     const int c0 = (int)blockIdx.x * NB;
     const int xrows = tall ? min(NB, below - c0) : 0;
     double* __restrict__ Xg = A + (long)(nb + (tall ? c0 : 0)) * lda;   // my 64 rows below the diagonal block
@@ -543,6 +628,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
                     acc[rt][ct][r] = base[(long)min(row, rmax) * lda + min(col, nb - 1)];
                 }
+        if (FUSED && fuse.prevK > 0) {
+            // part B: acc -= L[my rows, prev] L[rows of A_jj, prev]^T, the previous panel's columns sit directly left of A (and of Xg).
+            // Fragment loads as in panel_fused_product (k-slot (t, lk) = column 4 lk + t of a 16-column chunk); rows clamped like the
+            // loads above (clamped rows only feed accumulator entries that the padding fix-up below overwrites).
+            const double* __restrict__ pa[2]; const double* __restrict__ pbq[4];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) pa[rt] = base + (long)min(32 * (w & 1) + 16 * rt + li, rmax) * lda - fuse.prevK + 4 * lk;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) pbq[ct] = A + (long)min(16 * ct + li, nb - 1) * lda - fuse.prevK + 4 * lk;
+#pragma unroll 1
+            for (int kc = 0; kc < fuse.prevK; kc += 16) {
+                d4u a[2], b[4];
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) a[rt] = *reinterpret_cast<const d4u*>(pa[rt] + kc);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) b[ct] = *reinterpret_cast<const d4u*>(pbq[ct] + kc);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < 4; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[rt][t], b[ct][t], acc[rt][ct], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1567,6 +1677,7 @@ int g_left_looking_panels = 1;                                       // gpk_debu
 int g_panel_mfma = 1;                                                // gpk_debug_set key 21: 0 = first-design panel kernel (potf2_tile: two columns per barrier)
 int g_panel_unrolled = 1;                                            // gpk_debug_set key 41: 0 = the rolled instantiation of the panel kernel
 int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
+int g_panel_fused = 1;                                               // gpk_debug_set key 48: 0 = rank-64 updates as launches of their own between the panel kernels (round 2)
 int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
 inline int split(int n, int base = NB) {
@@ -1812,10 +1923,43 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
         if (ev_rec_pre) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));
         return 0;
     }
+    // FUSED schedule (g_panel_fused, default): the rank-64 work between two panels rides inside the panel kernels (PanelFuse above)
+    // Right-looking schedule (whole chip) only: on the 32-CU chain partition of the pipelined phase the product workgroups sit on the
+    // same CUs as the panel workgroups and slow them down (co-residence, the very reason for the CU partition): measured 3.13 -> 3.26 ms
+    // for the phase at config 2 with the left-looking chain fused, so that chain keeps its separate launches (g_panel_fused = 2 forces it).
+    const bool fused = g_panel_fused && (g_panel_fused == 2 || !left_looking) && g_fused_panel && g_panel_mfma == 1 && g_panel_unrolled && !ev_wait_p1 && !ev_rec_pre;
     for (int j0 = 0; j0 < ob; j0 += NB) {
         const int nb = (ob - j0 < NB) ? ob - j0 : NB;
         double* Ajj = A + (long)j0 * lda + j0;
         const int below = nrows - (j0 + nb);
+        if (fused) {
+            const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
+            const unsigned target = h->panel_loaded + (unsigned)nrb;
+            PanelFuse f;
+            memset(&f, 0, sizeof f);
+            f.npanel = 1 + nrb;
+            f.prevK = j0 > 0 ? NB : 0;                              // part B: the previous panel applied to this panel's columns
+            const int r1 = j0 + NB;                                  // first row / column behind this panel
+            if (j0 > 0 && r1 < ob && r1 < nrows) {
+                // part A (independent of this panel).  Left-looking: the block's panels 0 .. j-1 (all final) applied to the NEXT panel's
+                // columns, which then only lack panel j -- part B of the next kernel;
+                // right-looking: panel j-1 applied to all remaining columns of the block.  Rows from r1 down (rows above belong to the
+                // upper triangle of the block).
+                f.gm = nrows - r1;
+                f.gC = A + (long)r1 * lda + r1;
+                if (left_looking) { f.gn = std::min(NB, ob - r1); f.gK = j0;      f.gA = A + (long)r1 * lda; }
+                else              { f.gn = ob - r1;              f.gK = NB;      f.gA = A + (long)r1 * lda + (j0 - NB); }
+                f.gB = f.gA;                                         // rows r1 .. r1 + gn - 1 of the same columns
+                f.gtn = gpk_ceil_div(f.gn, NB);
+                if (f.gK <= 0 || f.gn <= 0 || f.gm <= 0) { f.gm = f.gn = f.gK = f.gtn = 0; }
+            }
+            const int extra = f.gK > 0 ? gpk_ceil_div(f.gm, PFM) * f.gtn : 0;
+            potrf_panel_mfma_kernel<8, true, true><<<1 + nrb + extra, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                                            (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg, f);
+            GPK_LAUNCH_CHECK(h);
+            h->panel_loaded = target;
+            continue;
+        }
         // (left-looking: the other columns are first touched by the second panel's update; right-looking: by the first panel's)
         if (ev_wait_p1 && j0 == (left_looking ? NB : 0)) GPK_HIP(h, hipStreamWaitEvent(h->stream, (hipEvent_t)ev_wait_p1, 0));
         if (left_looking && j0 > 0) {
@@ -1827,22 +1971,25 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             // 4.42 vs 4.25 ms for the phase), so it remains the default everywhere else.
             // (Tried in round 2: the contributions of the panels up to p-2 on a SECOND stream of the same partition, next to panel
             // p-1's kernel, so that only a rank-64 update stays between two panel kernels.  Not possible on this runtime: a fourth
-            // stream in use shares a hardware queue with one of the others -- CU mask included -- see pipe_setup.)
+            // stream in use shares a hardware queue with one of the others -- CU mask included -- see pipe_setup.  Round 3: the same
+            // idea INSIDE the panel kernel, see PanelFuse.)
             GPK_TRY(gpk_i_gemm(h, false, true, nrows - j0, nb, j0, -1.0, A + (long)j0 * lda, lda, A + (long)j0 * lda, lda, 1.0, Ajj, lda, false));
         }
         if (g_fused_panel) {
             const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
             const unsigned target = h->panel_loaded + (unsigned)nrb;
+            PanelFuse nofuse;
+            memset(&nofuse, 0, sizeof nofuse);
             if (g_panel_mfma == 2)
                 potrf_panel_la_kernel<<<1 + nrb, 320, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
                                                                        (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
             else if (g_panel_mfma) {
                 if (g_panel_unrolled)
                     potrf_panel_mfma_kernel<8, true><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                      (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+                                                                                      (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg, nofuse);
                 else
                     potrf_panel_mfma_kernel<8, false><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
+                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg, nofuse);
             }
             else
             potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
@@ -2187,6 +2334,7 @@ extern "C" int gpk_debug_set_pipeline_units(int v) { g_pipeline_units = v; retur
 extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0; }
 extern "C" int gpk_debug_set_left_looking_panels(int v) { g_left_looking_panels = v; return 0; }
 extern "C" int gpk_debug_set_panel_mfma(int v) { g_panel_mfma = v; return 0; }
+extern "C" int gpk_debug_set_panel_fused(int v) { g_panel_fused = v; return 0; }
 extern "C" int gpk_debug_set_potrf_pipeline(int key, int v) { (key == 19 ? g_potrf_pipeline_min_n : g_potrf_pipeline_max_n) = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {

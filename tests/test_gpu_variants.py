@@ -168,3 +168,64 @@ def test_burgers_leading_zero_layout_agrees_with_dense_schedule():
     assert np.linalg.norm(out[1][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
     np.testing.assert_allclose(out[1][1], hist_ref, rtol=1e-6)
     ctx.close()
+
+
+@pytest.mark.parametrize('n', [64, 65, 130, 1000, 2049, 4001])
+def test_fused_panel_schedule_matches_separate_update_launches(n):
+    """gpk_debug_set(48, .): the rank-64 work between two Cholesky panels rides inside the panel kernels (default: part B at the
+    start of the panel workgroups, part A in extra workgroups next to the factorisation) or runs as launches of its own (round 2).
+    Same factor up to rounding, same LAPACK info; the Gauss-Newton step (left-looking chain of the pipelined phase) likewise."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(n)
+    M = rng.normal(size=(n, n))
+    A0 = M @ M.T + n * np.eye(n)
+    out = []
+    try:
+        for fused in (1, 0):
+            ctx.lib.gpk_debug_set(48, fused)
+            A = ctx.array(A0)
+            assert ctx.potrf(A) == 0
+            out.append(np.tril(A.download()))
+            A.free()
+        Lref = np.linalg.cholesky(A0)
+        for L in out:
+            assert np.linalg.norm(L - Lref) <= 1e-12 * np.linalg.norm(A0)
+        assert np.linalg.norm(out[0] - out[1]) <= 1e-13 * np.linalg.norm(A0)
+        bad = A0.copy()
+        k = (2 * n) // 3
+        bad[k, k] = -1.0
+        ctx.lib.gpk_debug_set(48, 1)
+        A = ctx.array(bad)
+        assert ctx.potrf(A) == k + 1
+    finally:
+        ctx.lib.gpk_debug_set(48, 1)
+        ctx.close()
+
+
+def test_fused_panel_schedule_in_the_pipelined_gn_step():
+    import gpk
+    from oracle import gp_oracle as O
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(5)
+    Nd, Nb = 1700, 200                                            # n_z + 1 = 1701: pipelined product + factorisation (3 blocks and more)
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    z0 = rng.normal(size=Nd)
+    sols = []
+    try:
+        for fused in (2, 0):                                      # 2: also the left-looking chain of the pipelined phase (off by default there)
+            ctx.lib.gpk_debug_set(48, fused)
+            T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-9, 'adaptive')
+            assert ctx.potrf(T) == 0
+            prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0)
+            z = ctx.array(z0)
+            for _ in range(3):
+                loss, info = ctx.gn_step(prob, z)
+                assert info == 0
+            sols.append(z.download())
+            prob.release_workspace(); T.free()
+    finally:
+        ctx.lib.gpk_debug_set(48, 1)
+        ctx.close()
+    assert np.linalg.norm(sols[0] - sols[1]) <= 1e-9 * np.linalg.norm(sols[1])
