@@ -1036,7 +1036,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
     const bool big = (g_force_cfg == 1) && !g.tri_a;
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
-    if ((g_force_cfg == 4 || (g_force_cfg == 0 && g_big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_big_min)) && !g.tri_a && !lower_only)
+    if ((g_force_cfg == 4 || (g_force_cfg == 0 && g_big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_big_min)) && !g.tri_a && (!lower_only || g_force_cfg == 4))
         return launch_cfg<128, 128, 32, 32>(h, ta, tb, g);           // 16 waves, one workgroup per CU
     if ((g_force_cfg == 3 || (g_force_cfg == 0 && g_tall_min > 0 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_tall_min)) && !g.tri_a && !lower_only)
         return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);            // 8 waves, 2 workgroups per CU
