@@ -57,6 +57,10 @@ int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* hos
  * default sharded for world >= 4);  key 2: alignment of the column shards of the step (default 128) */
 int gpk_mg_set_option(gpk_mg_handle mg, int key, int value);
 
+/* Health check of the bound collectives (every rank calls it): a broadcast from rank 0 and an all-gather of small buffers,
+ * verified on the host; *host_ok = 1 if both delivered what they should. */
+int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok);
+
 /* gpk_potrf over all ranks: A (n x n, ld lda) holds the SAME symmetric matrix on every rank on entry and the complete
  * lower factor on every rank on return.  host_info: LAPACK info, identical on all ranks (one host read at the end). */
 int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info);

@@ -389,6 +389,39 @@ extern "C" int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, cons
     return 0;
 }
 
+// Round trip through the two bound collectives on small buffers: a broadcast from rank 0 and an all-gather, both checked on the
+// host.  With a communicator of one rank (all a one-GPU box can have) this is what proves that the dlsym'ed entry points are
+// called with the right argument order and data-type codes; with more ranks it is a cheap health check before the big buffers.
+extern "C" int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok) {
+    if (!mg || !host_ok) return GPK_ERR_ARG;
+    gpk_handle h = mg->h;
+    *host_ok = 0;
+    if (!mg->bcast || !mg->allgather) return gpk_bad_arg(h, "gpk_mg_selftest: no communicator bound");
+    const int P = mg->world, n = 1000;
+    double* d = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&d, (size_t)n * (P + 2) * sizeof(double)));
+    std::vector<double> host((size_t)n * (P + 2));
+    for (int i = 0; i < n; ++i) { host[i] = (mg->rank == 0) ? 1000.0 + i : -1.0; host[n + i] = 100.0 * mg->rank + 0.001 * i; }
+    int rc = 0;
+    hipError_t e = hipMemcpyAsync(d, host.data(), (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        int r = mg->bcast(d, d, (size_t)n, NCCL_DOUBLE, 0, mg->comm, (void*)h->stream);
+        if (r == 0) r = mg->allgather(d + n, d + 2 * n, (size_t)n, NCCL_DOUBLE, mg->comm, (void*)h->stream);
+        if (r != 0) rc = nccl_fail(mg, r, "self-test collective");
+    }
+    if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(host.data(), d, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return gpk_fail(h, e, "gpk_mg_selftest", __FILE__, __LINE__);
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) ok = host[i] == 1000.0 + i;
+    for (int r = 0; r < P && ok; ++r)
+        for (int i = 0; i < n && ok; ++i) ok = host[(size_t)(2 + r) * n + i] == 100.0 * r + 0.001 * i;
+    *host_ok = ok ? 1 : 0;
+    return 0;
+}
+
 extern "C" int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info) {
     if (!mg || !A || n < 0 || lda < n) return GPK_ERR_ARG;
     gpk_handle h = mg->h;

@@ -42,16 +42,36 @@ def column_bounds(ncols, lead, rows, world, align=128):
     return list(out)
 
 
-def torch_rccl_path():
-    """The RCCL library this process already uses: torch bundles one (torch/lib/librccl.so); else the ROCm one."""
+def loaded_hip_runtime():
+    """path of the libamdhip64 this process has mapped (None if none yet)"""
     try:
-        import torch
-        p = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        if os.path.exists(p):
-            return p
-    except Exception:
+        for line in open('/proc/self/maps'):
+            if 'libamdhip64.so' in line:
+                return line.split()[-1]
+    except OSError:
         pass
-    for p in ('/opt/rocm/lib/librccl.so.1', '/opt/rocm/lib/librccl.so'):
+    return None
+
+
+def torch_rccl_path():
+    """The RCCL library that belongs to the ROCm stack this process ACTUALLY runs on.  torch wheels bundle their own
+    libamdhip64 / libhsa-runtime64 / librccl under torch/lib; whichever of torch and libgpk.so is loaded first decides which
+    HIP runtime the process uses (same soname), and RCCL opens "its" HSA runtime by file name -- a librccl from the other tree
+    finds an uninitialised second copy and ncclCommInitRank fails with 'no ROCm-capable device is detected'.  So: the librccl
+    next to the mapped libamdhip64 (torch/lib when torch was imported first, as in bench.py; /opt/rocm/lib otherwise)."""
+    hip = loaded_hip_runtime()
+    cands = []
+    if hip:
+        d = os.path.dirname(hip)
+        cands += [os.path.join(d, 'librccl.so'), os.path.join(d, 'librccl.so.1')]
+    else:
+        try:
+            import torch
+            cands.append(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
+        except Exception:
+            pass
+    cands += ['/opt/rocm/lib/librccl.so.1', '/opt/rocm/lib/librccl.so']
+    for p in cands:
         if os.path.exists(p):
             return p
     return None
@@ -92,6 +112,8 @@ class MultiGpu:
         uid2 = (C.c_char * 128).from_buffer_copy(box[0])
         self.ctx._chk(self.lib.gpk_mg_rccl_init(self.h, pb, uid2))
         self.comm_kind = f'rccl ({path})'
+        if not self.selftest():                                    # argument order / data-type codes of the bound entry points
+            raise GpkError('gpk_mg: the RCCL collectives did not deliver the self-test pattern')
 
     def _init_staged(self, group):
         """ncclBroadcast / ncclAllGather stand-ins: wait for the stream, stage through host memory, torch.distributed (gloo)."""
@@ -143,6 +165,12 @@ class MultiGpu:
     def set_option(self, key, value):
         keys = {'lookahead': 0, 'shard_hb': 1, 'col_align': 2}
         self.ctx._chk(self.lib.gpk_mg_set_option(self.h, keys[key] if isinstance(key, str) else int(key), int(value)))
+
+    def selftest(self):
+        """round trip through the bound collectives on small buffers (every rank calls it) -> True / False"""
+        ok = C.c_int()
+        self.ctx._chk(self.lib.gpk_mg_selftest(self.h, C.byref(ok)))
+        return bool(ok.value)
 
     def potrf(self, A_ptr, n, lda):
         """In-place lower Cholesky over all ranks (A replicated on entry, the full factor on every rank on return) -> info"""

@@ -84,10 +84,11 @@ def test_rccl_binding_comes_up_with_one_rank():
     collectives bound: what bench.py does on every rank of the 8-GPU run, minus the peers."""
     import ctypes as C
     import gpk
-    from gpk.mg import torch_rccl_path
+    from gpk.mg import loaded_hip_runtime, torch_rccl_path
     ctx = gpk.Context(0)
-    path = torch_rccl_path()
-    assert path is not None
+    path = torch_rccl_path()                                      # the librccl of the ROCm stack this process runs on (see its docstring)
+    assert path is not None and os.path.dirname(path) == os.path.dirname(loaded_hip_runtime())
+    print('\n[rccl] HIP runtime', loaded_hip_runtime(), '-> RCCL', path)
     uid = (C.c_char * 128)()
     assert ctx.lib.gpk_mg_rccl_unique_id(path.encode(), uid) == 0
     assert any(b != 0 for b in uid.raw)
@@ -95,6 +96,9 @@ def test_rccl_binding_comes_up_with_one_rank():
     assert ctx.lib.gpk_mg_create(ctx.h, 0, 1, 512, C.byref(h)) == 0
     rc = ctx.lib.gpk_mg_rccl_init(h, path.encode(), uid)
     assert rc == 0, ctx.lib.gpk_last_error(ctx.h).decode()
+    ok = C.c_int()
+    rc = ctx.lib.gpk_mg_selftest(h, C.byref(ok))                  # the REAL ncclBroadcast / ncclAllGather, one rank: argument order, type codes
+    assert rc == 0 and ok.value == 1, ctx.lib.gpk_last_error(ctx.h).decode()
     assert ctx.lib.gpk_mg_destroy(h) == 0
     ctx.close()
 
@@ -127,6 +131,7 @@ WORKER = textwrap.dedent('''
     z0 = rng.normal(size=nz)
     sol_ref, hist_ref = O.gn_method(sysm, [Lref], z0, 3, 1)
     mgpu = MultiGpu(ctx, rank, world, panel=128, comm='staged')
+    assert mgpu.selftest()
     mgpu.set_option('col_align', 64)
     results = []
     for lookahead, shard_hb in ((0, 0), (1, 0), (1, 1)):
