@@ -88,13 +88,12 @@ class MultiGpu:
         ctx._chk(self.lib.gpk_mg_create(ctx.h, self.rank, self.world, self.panel, C.byref(h)))
         self.h = h
         self._keep = []
-        if self.world > 1:
-            if comm == 'rccl':
-                self._init_rccl(group)
-            elif comm == 'staged':
-                self._init_staged(group)
-            else:
-                raise ValueError("world > 1 needs comm='rccl' or comm='staged'")
+        if comm == 'rccl':                                         # (also with one rank when asked for: the binding and the self-test run)
+            self._init_rccl(group)
+        elif comm == 'staged':
+            self._init_staged(group)
+        elif self.world > 1:
+            raise ValueError("world > 1 needs comm='rccl' or comm='staged'")
 
     # ---- communicators ------------------------------------------------------------------------------------------------
     def _init_rccl(self, group):
@@ -108,7 +107,8 @@ class MultiGpu:
             if rc != 0:
                 raise GpkError(f'gpk_mg_rccl_unique_id failed ({rc}); library {path}')
         box = [bytes(uid.raw) if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)      # 128 bytes through the process group's own transport
+        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+            dist.broadcast_object_list(box, src=0, group=group)  # 128 bytes through the process group's own transport
         uid2 = (C.c_char * 128).from_buffer_copy(box[0])
         self.ctx._chk(self.lib.gpk_mg_rccl_init(self.h, pb, uid2))
         self.comm_kind = f'rccl ({path})'

@@ -103,6 +103,43 @@ def test_rccl_binding_comes_up_with_one_rank():
     ctx.close()
 
 
+def test_rccl_communicator_next_to_torchs_nccl_process_group(tmp_path):
+    """What every rank of `bench.py --gpus N` does before the sharded run, with N = 1: torch.distributed on the nccl backend (its own
+    RCCL communicator), the unique id through broadcast_object_list on that group, a SECOND communicator created by libgpk from the
+    same RCCL library, the self-test through ncclBroadcast / ncclAllGather, then a factorisation and a step through gpk_mg_*."""
+    script = tmp_path / 'one_rank.py'
+    script.write_text(textwrap.dedent(f'''
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'nonlinpdes-gpsolver_amd'))
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl')
+        t = torch.ones(4, device='cuda'); dist.all_reduce(t); torch.cuda.synchronize()      # torch's communicator exists
+        import gpk
+        from gpk.mg import MultiGpu
+        from oracle import gp_oracle as O
+        ctx = gpk.Context(0)
+        mgpu = MultiGpu(ctx, 0, 1, panel=256, comm='rccl')
+        assert 'torch/lib/librccl' in mgpu.comm_kind, mgpu.comm_kind
+        assert mgpu.selftest()
+        rng = np.random.RandomState(3)
+        Nd, Nb = 400, 80
+        Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+        Theta = O.add_nugget(O.gram_matrix_assembly(Xd, Xb), 'Nonlinear_elliptic', Nd, Nb, 1e-7)[0]
+        T = ctx.array(Theta)
+        assert mgpu.potrf(T.ptr, 2 * Nd + Nb, T.ld) == 0
+        assert np.max(np.abs(np.tril(T.download()) - O.cholesky(Theta))) <= 1e-9 * np.max(np.abs(Theta))
+        dist.barrier(); dist.destroy_process_group()
+        mgpu.close(); ctx.close()
+        print('ok')
+    '''))
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'ok' in p.stdout, p.stderr[-3000:]
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
