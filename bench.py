@@ -733,6 +733,8 @@ def main():
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
         dist.init_process_group(os.environ.get('GPK_BENCH_BACKEND', 'nccl'))   # (gloo only in the CPU flow test)
+        dist.barrier()                                            # creates the communicator NOW (RCCL prints its version banner to stdout
+                                                                  # when it does: it must not come after the JSON line)
     workload = args.workload if args.workload != 'auto' else 'c2'
     rank = int(os.environ.get('RANK', '0'))
     if args.sharded_path or workload == 'c5':
@@ -768,6 +770,10 @@ def main():
     # the ONE line goes out before anything that can still block (a peer that died after its last collective would otherwise
     # leave rank 0 in the final barrier with the result unprinted)
     if out is not None:
+        try:                                                      # RCCL prints a version banner through C stdio (fully buffered when stdout is
+            C.CDLL(None).fflush(None)                             # a pipe): flush it NOW so that the JSON line is the last thing on stdout
+        except Exception:                                         # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if use_pg:
         import threading
