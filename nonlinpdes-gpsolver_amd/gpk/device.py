@@ -16,10 +16,16 @@ DINV_BLOCK = int(__import__('os').environ.get('GPK_DINV_BLOCK', '0'))   # rows p
 def dinv_block_for(n):
     """Rows per inverted diagonal block for a factor of order n: GPK_DINV_BLOCK when set, else 1024, or 2048 from order 6000 on (the
     solve phase then has 5 instead of 9 triangular products at BASELINE config 2: 3.3 -> 3.15 ms per step; iterates agree with the
-    substitution path to ~1e-12 there, tests/test_gpu_parity.py::test_trsm_dinv and DESIGN.md section 4 'Numerics')."""
+    substitution path to ~1e-12 there, tests/test_gpu_parity.py::test_trsm_dinv and DESIGN.md section 4 'Numerics') -- but never more
+    than a quarter of the order (round 3, advisor): multiplying by an explicit inverse is only conditionally stable, and a block that
+    is half the matrix (1024 rows at BASELINE config 1, order 1924) made the iterates differ from the substitution path by 3e-10
+    instead of 3e-13.  Orders up to 1024 get 256-row blocks."""
     if DINV_BLOCK:
         return DINV_BLOCK
-    return 2048 if n >= 6000 else 1024
+    db = 2048 if n >= 6000 else 1024
+    while db > 256 and db > n // 4:
+        db //= 2
+    return db
 SYSTEM = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_flow2d': 3, 'Nonlinear_elliptic_relaxed': 4}
 
 
