@@ -24,6 +24,8 @@ struct gpk_ctx {
     double* d_scalars = nullptr;    // small device scratch for reductions (16 doubles)
     int* d_flags = nullptr;         // per-block "solved" epochs of the fused single-vector triangular solve (GPK_MAX_TRSV_BLOCKS ints)
     int trsv_epoch = 0;
+    void* d_trsv_gran = nullptr;    // {value, epoch} granules of the fused triangular solve with data-tagged hand-offs (64 per block), allocated on first use
+    long long trsv_gran_epoch = 0;
     int* d_obflags = nullptr;       // 64 flags of the persistent outer-block Cholesky kernel (epoch-tagged)
     int ob_epoch = 0;
     unsigned panel_loaded = 0;      // running total of "diagonal block loaded" tickets issued to the Cholesky panel kernel (d_flags[GPK_MAX_TRSV_BLOCKS])

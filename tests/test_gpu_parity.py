@@ -325,17 +325,26 @@ def test_trsm_dinv(ctx, n, nrhs, lead, block):
         ctx.trsm_dinv(dL, D, dB, dB)                              # aliasing is refused
 
 
+@pytest.mark.parametrize('mode', [1, 2, 0])                       # data-tagged hand-offs (default), flags, two launches per block
 @pytest.mark.parametrize('n', [1, 64, 100, 1000, 3001])
-def test_trsv_and_potrs(ctx, n):
+def test_trsv_and_potrs(ctx, n, mode):
     rng = np.random.RandomState(n)
     A = _spd(rng, n)
     b = rng.normal(size=n)
     dA = ctx.array(A)
     assert ctx.potrf(dA) == 0
-    db = ctx.array(b)                                        # contiguous vector -> single-vector path
-    ctx.potrs(dA, db)
-    x = db.download()
+    ctx.lib.gpk_debug_set(4, mode)
+    try:
+        xs = []
+        for _ in range(3):                                        # repeated: the tags / flags of earlier solves must not satisfy a later one
+            db = ctx.array(b)                                     # contiguous vector -> single-vector path
+            ctx.potrs(dA, db)
+            xs.append(db.download())
+    finally:
+        ctx.lib.gpk_debug_set(4, 1)
+    x = xs[0]
     assert np.linalg.norm(A @ x - b) <= 1e-11 * np.linalg.norm(A) * np.linalg.norm(x)
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
 
 
 # ------------------------------------------------------------------------------------------------ Gauss-Newton

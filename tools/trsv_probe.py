@@ -15,14 +15,14 @@ for n in (4000, 4001, 8400, 100, 64, 1):
     for trans in (0, 1):
         ref = np.linalg.solve(Lh.T if trans else Lh, b)
         out = []
-        for fused in (1, 0):
+        for fused in (1, 2, 0):
             ctx.lib.gpk_debug_set(4, fused)
             best = 1e9
             for rep in range(4):
                 x = ctx.array(b)
                 ctx.synchronize(); ctx.timer_start(); ctx.trsm(L, x, trans=bool(trans)); best = min(best, ctx.timer_stop())
             err = np.max(np.abs(x.download().ravel() - ref)) / np.max(np.abs(ref))
-            out.append('%s %.1f us err %.1e' % ('fused' if fused else 'split', best * 1e3, err))
+            out.append("%s %.1f us err %.1e" % ({1: "granules", 2: "flags", 0: "split"}[fused], best * 1e3, err))
         print('n=%5d trans=%d: %s' % (n, trans, ' | '.join(out)))
     L.free()
 ctx.lib.gpk_debug_set(4, 1)
