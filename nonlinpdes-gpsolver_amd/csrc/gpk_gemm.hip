@@ -64,6 +64,7 @@ struct GemmArgs {
     int ntm, ntn, ntiles;
     int ntm_full;      // tri_a: number of row tiles of C (ntm counts PAIRS of them then)
     int band;          // > 0: leading-zero launches are ordered in bands of this many row tiles (see map_tile)
+    int row_order;     // leading-zero launches without bands: 1 = row-major tile order, contiguous per XCD (see map_tile)
     int nsuper;        // > 0: supertile schedule of the lower-triangular, leading-zero (SYRK) launch, see map_tile
     int splitk;        // > 1: every tile's K range is cut into `splitk` chunks, one workgroup each (blockIdx = tile * splitk + chunk);
                        // the chunks leave their accumulators in `ws`, take a ticket in cnt[tile], and the LAST arriver adds them up in
@@ -226,6 +227,17 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
             const int rem = b - bd * per;
             tn = g.ntn - 1 - rem / rows;
             tm = r0 + rem % rows;
+        } else if (g.row_order) {
+            // ROW-major, one contiguous run of tile rows per XCD (block b runs on XCD b % 8): the tiles (tm, all tn) of a row --
+            // which read the same 64 columns of A over nearly the same K range -- run back to back on ONE XCD, so that panel comes
+            // from memory once per row instead of once per tile; the few column panels of B (ntn x K x 64 doubles) are what is
+            // re-read, and they fit the Infinity Cache.  For the 512-column products of the pipelined phase (ntn = 8, see
+            // gpk_factor.hip): column-major order re-reads the 269 MB of S eight times per product.  EXPERIMENT, off by default: measured
+            // slower (see g_row_order).
+            const int nwg2 = g.ntiles, xcd2 = b & 7, q2 = nwg2 >> 3, r2 = nwg2 & 7;
+            const int l2 = (xcd2 < r2 ? xcd2 * (q2 + 1) : r2 * (q2 + 1) + (xcd2 - r2) * q2) + (b >> 3);
+            tm = l2 / g.ntn;
+            tn = g.ntn - 1 - (l2 - tm * g.ntn);
         } else {
             tn = g.ntn - 1 - b / g.ntm;                               // column-major from the longest column, as above
             tm = b % g.ntm;
@@ -500,7 +512,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
             GPK_CP(M) GPK_CP(N) GPK_CP(K) GPK_CP(alpha) GPK_CP(beta) GPK_CP(A) GPK_CP(lda) GPK_CP(B) GPK_CP(ldb) GPK_CP(C) GPK_CP(ldc)
             GPK_CP(lower_only) GPK_CP(lead_div) GPK_CP(lead) GPK_CP(skip_upper) GPK_CP(stagger) GPK_CP(rev_k) GPK_CP(tri_a) GPK_CP(vecA) GPK_CP(vecB)
             GPK_CP(ntm) GPK_CP(ntn) GPK_CP(ntiles) GPK_CP(ntm_full) GPK_CP(band) GPK_CP(nsuper) GPK_CP(splitk) GPK_CP(ws) GPK_CP(cnt)
-            GPK_CP(sk_segs) GPK_CP(sk_off)
+            GPK_CP(sk_segs) GPK_CP(sk_off) GPK_CP(row_order)
 #undef GPK_CP
             // (wave-uniform by construction: through SGPRs, so that the loop costs no vector registers)
             const int* q = reinterpret_cast<const int*>(g.sk_segs + si);
@@ -629,6 +641,7 @@ int g_sk = 1;                                                        // gpk_debu
 int g_sk_rounds = 6;                                                 // gpk_debug_set key 43: automatic mode uses tile lists for launches of fewer than this many rounds of resident workgroups
 int g_sk_stagger = 2;                                                // gpk_debug_set key 45: start stagger of the co-resident workgroups of a tile-list launch (slot x this x 512 cycles; every workgroup starts at once and has the same amount of work -- without it the four workgroups of a CU run in lock-step, see the kernel)
 int g_sk_rowclass = 1;                                               // gpk_debug_set key 46: 0 = keep the launch's tile order when cutting shares (experiment)
+int g_row_order = 0;                                                 // gpk_debug_set key 49: 1 = row-major, per-XCD-contiguous tile order for the narrow leading-zero products of the pipelined phase (experiment, round 3: fewer re-reads of S by construction, but slower -- sum of the product launches 2.14 -> 2.31 ms, phase 3.20 -> 3.39 ms at config 2, tools/row_order_ab.sh: longest-column-first matters more than the traffic)
 int g_sk_snap = 4;                                                   // gpk_debug_set key 44: a share boundary closer than this many slabs to a tile boundary moves there
 
 struct SkKey {
@@ -846,6 +859,7 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
     }
     g.band = 0;
+    g.row_order = (g_row_order && g.lead > 0 && !g.lower_only && !g.tri_a && g.skip_upper && g.ntn <= 16) ? 1 : 0;
     if (g.lead > 0 && g.lower_only && g_syrk_band > 0) {
         const double panel = (double)BM * g.K * sizeof(double);       // one column panel of S
         if ((double)g.ntm * panel > 4.0 * g_syrk_band * 1048576.0) {
@@ -996,6 +1010,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 45) { g_sk_stagger = value; return 0; }
     if (key == 46) { g_sk_rowclass = value; return 0; }
     if (key == 47) { extern int g_asm_pairs; g_asm_pairs = value; return 0; }
+    if (key == 49) { g_row_order = value; return 0; }
     return GPK_ERR_ARG;
 }
 
@@ -1023,7 +1038,7 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.stagger = g_stagger;
     g.band = 0; g.splitk = 1; g.ws = nullptr; g.cnt = nullptr; g.nsuper = 0; g.ntm_full = 0;   // (set per launch configuration below)
-    g.sk_segs = nullptr; g.sk_off = nullptr;
+    g.sk_segs = nullptr; g.sk_off = nullptr; g.row_order = 0;
     g.rev_k = (g_rev_k && g.lead > 0) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
