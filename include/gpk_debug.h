@@ -36,6 +36,11 @@ int gpk_ubench_cu_census(gpk_handle h, int first_bit, int nbits, int nblocks, in
 int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,
                             double* host_ms3);
 
+/* EXPERIMENT (round 3): plain NN product C = A B with the operand feed through LDS-DMA (global_load_lds) instead of global ->
+ * VGPR -> LDS; same tile as the product kernel.  M, N multiples of 64, K of 16, even leading dimensions, 16-byte aligned A, B.
+ * csrc/gpk_gemm_dma_probe.hip, tools/gemm_dma_probe.py. */
+int gpk_debug_gemm_dma(gpk_handle h, int m, int n, int k, const double* A, int lda, const double* B, int ldb, double* C, int ldc);
+
 #ifdef __cplusplus
 }
 #endif

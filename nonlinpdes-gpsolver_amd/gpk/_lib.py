@@ -98,6 +98,7 @@ PROTOTYPES = {
     'gpk_ubench_latency': (_i, [_vp, _i, _pd]),
     'gpk_ubench_xcc_map': (_i, [_vp, _i, _i, _pi]),
     'gpk_ubench_cu_census': (_i, [_vp, _i, _i, _i, _pi]),
+    'gpk_debug_gemm_dma': (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
     'gpk_debug_overlap_probe': (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _vp, _i, _pd]),
 }
 

@@ -132,3 +132,22 @@ def test_cholesky_and_gn_step_with_tile_lists_everywhere(ctx):
             _auto(ctx)
     assert np.array_equal(sols[0], sols[1])
     assert np.linalg.norm(sols[0] - sols[2]) <= 1e-9 * np.linalg.norm(sols[2])
+
+
+def test_lds_dma_feed_probe_kernel(ctx):
+    """the LDS-DMA experiment kernel (gpk_debug_gemm_dma, csrc/gpk_gemm_dma_probe.hip; not on the product path): same bits as the
+    product kernel -- same tile, same summation order -- on shapes with several K slabs and tiles"""
+    rng = np.random.RandomState(3)
+    for m, n, k in ((64, 64, 16), (192, 256, 208), (640, 128, 1024)):
+        A = rng.normal(size=(m, k)); B = rng.normal(size=(k, n))
+        dA, dB, dC, dR = ctx.array(A), ctx.array(B), ctx.empty(m, n), ctx.empty(m, n)
+        assert ctx.lib.gpk_debug_gemm_dma(ctx.h, m, n, k, dA.ptr, dA.ld, dB.ptr, dB.ld, dC.ptr, dC.ld) == 0
+        ctx.lib.gpk_debug_set(0, 2)
+        try:
+            ctx.gemm(0, 0, m, n, k, 1.0, dA, dB, 0.0, dR)
+        finally:
+            ctx.lib.gpk_debug_set(0, 0)
+        got = dC.download()
+        assert np.max(np.abs(got - A @ B)) <= 1e-13 * (np.abs(A) @ np.abs(B)).max()
+        assert np.array_equal(got, dR.download())
+    assert ctx.lib.gpk_debug_gemm_dma(ctx.h, 65, 64, 16, dA.ptr, dA.ld, dB.ptr, dB.ld, dC.ptr, dC.ld) < 0      # shape restrictions are checked
