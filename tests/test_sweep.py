@@ -27,3 +27,30 @@ def test_sweep_runs_and_prefers_a_sane_lengthscale(capsys):
     by = {r['sigma']: r for r in recs}
     assert by[0.2]['test_L2_err'] < by[0.05]['test_L2_err']          # sigma = 0.05 under-resolves at 400 points
     assert '[Sweep] best test L2 error' in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_sweep_two_ranks_share_the_grid(tmp_path):
+    """two replicas (ranks) of the sweep on the one GPU of the test box, records gathered over gloo: every cell solved exactly once,
+    same numbers as the single-rank run"""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    args = ['--sigmas', '0.15', '0.2', '0.25', '--nuggets', '1e-10', '1e-8', '--N_domain', '300', '--N_boundary', '60', '--GNsteps', '4']
+    script = os.path.join(ROOT, 'nonlinpdes-gpsolver_amd', 'sweep.py')
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, script] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    recs = [json.loads(l) for l in outs[0][0].splitlines() if l.startswith('{')]
+    assert len(recs) == 6 and not [l for l in outs[1][0].splitlines() if l.startswith('{')]      # rank 0 reports, rank 1 is silent
+    import sweep
+    single = sweep.main(args)
+    key = lambda r: (r['sigma'], r['nugget'])
+    assert sorted(map(key, recs)) == sorted(map(key, single))
+    for a, b in zip(sorted(recs, key=key), sorted(single, key=key)):
+        assert a['chol_info'] == b['chol_info'] == 0
+        assert a['test_L2_err'] == pytest.approx(b['test_L2_err'], rel=1e-6)
