@@ -138,6 +138,7 @@ int g_k64_small = 1;                                                 // gpk_debu
 int g_band_mb = 192;                                                 // gpk_debug_set key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
 int g_syrk_band = 256;                                               // gpk_debug_set key 36: MB of S per band of a large leading-zero SYRK launch (0 = column-major over all rows).  North-star size, the product S^T S: no bands 24.15 ms, 192 MB 23.4, 256 MB 22.9, 384 MB 23.55, 512 MB 24.3
 int g_big_min = 6000;                                                 // gpk_debug_set key 38: launches with at least this many 64 x 64 tiles use the 128 x 128 tile with 16 waves, one workgroup per CU (0 = never).  tools/gemm_big_probe.py, 64 x 64 -> 128 x 64 -> this: NN 10500^3 60.0 / 58.6 / 65.2 TF/s, 8192^3 62.2 / 60.9 / 69.1 on a slow box; north-star solve phase 44.6 -> 43.7 ms with thresholds 3000 .. 6000; at config 2 (threshold 2000) the solve phase loses 5 %
+int g_big_lower_min = 8000;                                          // gpk_debug_set key 50: lower-triangular leading-zero launches (S^T S) with at least this many lower 64 x 64 tiles use the 128 x 128 / 16-wave tile (0 = never)
 int g_tall_min = 1500;                                               // gpk_debug_set key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
 int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
 int g_rev_k = 0;                                                     // gpk_debug_set key 16
@@ -1011,6 +1012,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 46) { g_sk_rowclass = value; return 0; }
     if (key == 47) { extern int g_asm_pairs; g_asm_pairs = value; return 0; }
     if (key == 49) { g_row_order = value; return 0; }
+    if (key == 50) { g_big_lower_min = value; return 0; }
     return GPK_ERR_ARG;
 }
 
@@ -1051,7 +1053,10 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
     const bool big = (g_force_cfg == 1) && !g.tri_a;
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
-    if ((g_force_cfg == 4 || (g_force_cfg == 0 && g_big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_big_min)) && !g.tri_a && (!lower_only || g_force_cfg == 4))
+    // (lower-triangular output with leading zeros = the product S^T S: from ~8000 lower 64 x 64 tiles on -- n_z ~ 8000 -- the 128 x 128 tile's
+    // halved operand traffic wins: north-star size 23.9 -> 22.2 ms; at config 2, 2016 tiles, it loses: 1.59 -> 2.07 ms)
+    const bool big_lower = lower_only && g.lead > 0 && g_force_cfg == 0 && g_big_lower_min > 0 && (long)gpk_ceil_div(m, 64) * (gpk_ceil_div(m, 64) + 1) / 2 >= g_big_lower_min;
+    if ((g_force_cfg == 4 || big_lower || (g_force_cfg == 0 && g_big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_big_min)) && !g.tri_a && (!lower_only || g_force_cfg == 4 || big_lower))
         return launch_cfg<128, 128, 32, 32>(h, ta, tb, g);           // 16 waves, one workgroup per CU
     if ((g_force_cfg == 3 || (g_force_cfg == 0 && g_tall_min > 0 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_tall_min)) && !g.tri_a && !lower_only)
         return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);            // 8 waves, 2 workgroups per CU
