@@ -2123,9 +2123,10 @@ extern int g_pipeline;
 int g_potrf_pipeline_min_n = 2048, g_potrf_pipeline_max_n = 0;      // gpk_debug_set keys 19 / 20: plain Cholesky pipelined for orders in
                                                                      // [min, max] (max = 0: off, see gpk_i_potrf)
 
+int g_potrf_ob = 512;                                                // gpk_debug_set key 51: outer block width of the right-looking factorisation (multiple of 64)
 static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     if (n <= 0) return 0;
-    constexpr int OB = 512;
+    const int OB = (g_potrf_ob >= 64 && g_potrf_ob % 64 == 0) ? g_potrf_ob : 512;
     for (int k0 = 0; k0 < n; k0 += OB) {
         const int ob = (n - k0 < OB) ? n - k0 : OB;
         GPK_TRY(gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, ob, lda, pivot_base + k0));
@@ -2444,6 +2445,7 @@ extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0;
 extern "C" int gpk_debug_set_left_looking_panels(int v) { g_left_looking_panels = v; return 0; }
 extern "C" int gpk_debug_set_panel_mfma(int v) { g_panel_mfma = v; return 0; }
 extern "C" int gpk_debug_set_panel_fused(int v) { g_panel_fused = v; return 0; }
+extern "C" int gpk_debug_set_potrf_ob(int v) { g_potrf_ob = v; return 0; }
 extern "C" int gpk_debug_set_potrf_pipeline(int key, int v) { (key == 19 ? g_potrf_pipeline_min_n : g_potrf_pipeline_max_n) = v; return 0; }
 
 extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {

@@ -969,6 +969,7 @@ extern "C" int gpk_debug_set_left_looking_panels(int v);
 extern "C" int gpk_debug_set_potrf_pipeline(int key, int v);
 extern "C" int gpk_debug_set_panel_mfma(int v);
 extern "C" int gpk_debug_set_panel_fused(int v);
+extern "C" int gpk_debug_set_potrf_ob(int v);
 
 extern "C" int gpk_debug_set(int key, int value) {
     if (key == 0) { g_force_cfg = value; return 0; }
@@ -999,6 +1000,7 @@ extern "C" int gpk_debug_set(int key, int value) {
     if (key == 19 || key == 20) return gpk_debug_set_potrf_pipeline(key, value);
     if (key == 21) return gpk_debug_set_panel_mfma(value);
     if (key == 48) return gpk_debug_set_panel_fused(value);
+    if (key == 51) return gpk_debug_set_potrf_ob(value);
     if (key == 16) { g_rev_k = value; return 0; }
     if (key == 25) { g_force_splitk = value; return 0; }
     if (key == 33) { g_tall_min = value; return 0; }
