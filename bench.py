@@ -45,7 +45,11 @@ WORKLOADS = {
     'c2': (4000, 400, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=4000 N_boundary=400 (BASELINE config 2)'),
     'c5': (16000, 2000, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=16000 N_boundary=2000 (BASELINE config 5)'),
     'n10k': (10000, 1000, 4, 'NonLinElliptic2d Gaussian sigma=0.2 N_domain=10000 N_boundary=1000 (north-star target size)'),
+    # the two non-elliptic BASELINE configurations (run_system below): same step, other Gram layouts / Gauss-Newton systems
+    'c3': (2000, 400, 8, 'Burgers1d anisotropic_Gaussian sigma=[0.3,0.05] N_domain=2000 N_boundary=400 (->399) nugget 1e-5 seed 0 (BASELINE config 3)'),
+    'c4': (1600, 200, 8, 'DarcyFlow2d inverse problem Gaussian sigma=0.2 N_domain=1600 N_boundary=200 N_data=60 noise=1e-3 nugget 1e-8 seed 9999 (BASELINE config 4)'),
 }
+PARITY_TOL = 1e-6                 # north star: device iterate within 1e-6 relative of the reference path on the same points
 SIGMA, ALPHA, M_EXP = 0.2, 1.0, 3.0
 
 
@@ -145,23 +149,28 @@ def trsm_dinv_executed_flops(N, nz, db=1024, num_cu=256, nb=64, bk=16, c0=0, c1=
     return acc[0], acc[1]
 
 
-def stored_pmc_traffic(which='syrk'):
+def stored_pmc_traffic(which='syrk', workload='c2'):
     """`roofline.traffic` cannot be measured inside this process (PMC counters need a rocprofv3 --pmc pass of their own,
-    tools/profile_round.sh): it is READ from the newest committed profiles/rNN_pmc_<which>.json -- HBM-side bytes per
-    Gauss-Newton step of that kernel family (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md) -- and labelled as such."""
+    tools/profile_round.sh): it is READ from the newest committed PMC pass OF THE SAME WORKLOAD -- profiles/rNN_pmc_<which>.json for
+    BASELINE config 2 (the historical name), profiles/rNN_pmc_<which>_<workload>.json for every other one; the file's own `workload`
+    field must agree -- HBM-side bytes per Gauss-Newton step of that kernel family (FETCH_SIZE x2 + WRITE_SIZE,
+    MI355X_MICROARCH.md).  No file for the workload: traffic is null (never another workload's bytes)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_pmc_{which}.json')))
+    suffix = '' if workload == 'c2' else f'_{workload}'
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r[0-9][0-9]_pmc_{which}{suffix}.json')))
     for path in reversed(files):
         try:
             d = json.load(open(path))
         except Exception:
             continue
+        if d.get('workload', 'c2') != workload:
+            continue
         v = d.get('hbm_bytes_per_step', d.get('hbm_bytes_per_launch'))
         if v is not None:
             per = 'step (sum over the launches of this kernel in one Gauss-Newton step)' if 'hbm_bytes_per_step' in d else 'launch'
             return v, (f'stored PMC pass profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of the same '
-                       f'kernel at this workload), bytes per {per}; not measured in this run')
-    return None, 'no stored PMC pass found'
+                       f'kernel at workload {workload}), bytes per {per}; not measured in this run')
+    return None, f'no stored PMC pass for workload {workload}'
 
 
 class AbortWatch:
@@ -181,7 +190,7 @@ class AbortWatch:
         if use_store:
             import torch.distributed as dist
             self.store = dist.distributed_c10d._get_default_store()
-        self.deadline = time.monotonic() + float(os.environ.get('GPK_SHARDED_TIMEOUT', '420'))
+        self.deadline = time.monotonic() + float(os.environ.get('GPK_SHARDED_TIMEOUT', '600'))
         self.done = threading.Event()
         self.lock = threading.Lock()                              # main thread and watcher may both get here: ONE line only
         self.thread = threading.Thread(target=self._poll, daemon=True)
@@ -272,11 +281,17 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     nugget, info = 1e-13, -1
     asm_ms = chol_ms = None
     while True:
+        ctx.prof_enable(True)                                     # (HIP events around the evaluator launch itself: gpk_prof_read_assembly)
+        asm_kernel_ms = None
         for rep in range(3):                                      # warm + 2 timed
             ctx.timer_start()
             ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, dXd.ptr, Nd, dXb.ptr, Nb, nugget, 2, T.ptr, T.ld, ratios))
             ms = ctx.timer_stop()
             asm_ms = ms if rep == 1 else min(asm_ms or ms, ms)
+            if rep >= 1:
+                k_ms = ctx.prof_read_assembly()
+                asm_kernel_ms = k_ms if asm_kernel_ms is None else min(asm_kernel_ms, k_ms)
+        ctx.prof_enable(False)
         ctx.timer_start()
         info = ctx.potrf(T)
         chol_ms = ctx.timer_stop()
@@ -297,6 +312,7 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     dinv_block = prob.struct.dinv_block
     z = ctx.array(z0)
     prob.workspace()
+    dev_first = first_step_on_device(ctx, prob, z0)               # for `parity` (also the first, code-object-loading step)
     losses = []
     for _ in range(args.warmup):
         losses.append(ctx.gn_step(prob, z)[0])
@@ -338,13 +354,20 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     syrk_launched = syrk_pipelined_flops(N, nz) if pipelined else syrk_flops
     syrk_dense = float(N) * (nz + 1) ** 2                        # dense symmetric count, SURVEY 8d ("SYRK N n_z^2")
     achieved = syrk_flops / (syrk_ms * 1e-3) / 1e12
-    traffic, traffic_source = stored_pmc_traffic('syrk')
-    trsm_traffic, trsm_traffic_source = stored_pmc_traffic('trsm_gemm')
+    traffic, traffic_source = stored_pmc_traffic('syrk', workload)
+    trsm_traffic, trsm_traffic_source = stored_pmc_traffic('trsm_gemm', workload)
     # dominant kernel of the step: gemm_f64_kernel<NN> = the whole solve phase S = L^{-1}[A | F] (GEMMs only since round 2)
     trsm_ms = prof['trsm_ms'] / steps
     uses_dinv = prob.Dinv is not None and os.environ.get('GPK_DEBUG_SET', '').find('10=0') < 0
     trsm_flops, trsm_launches = trsm_dinv_executed_flops(N, nz, gpk.device.dinv_block_for(N)) if uses_dinv else (None, None)
     trsm_achieved = trsm_flops / (trsm_ms * 1e-3) / 1e12 if trsm_flops else None
+    # the same quantities counted by the launch logic itself while the steps ran (gpk_prof_read_flops): must agree with the models
+    counted = {'solve_flops_per_step': prof['solve_flops'] / steps, 'solve_launches_per_step': prof['solve_launches'] / steps,
+               'product_flops_per_step': prof['product_flops'] / steps, 'product_launches_per_step': prof['product_launches'] / steps,
+               'cholesky_H_update_flops_per_step': prof['potrf_update_flops'] / steps,
+               'note': 'flops executed by the matrix-product launches of the timed steps, accumulated inside libgpk from the K range of every tile '
+                       '(gpk_prof_read_flops); the host-side models used for the rooflines (flops_per_step / flops_per_launch) must match: '
+                       'solve model %.6e, product model (launched tiles) %.6e' % (trsm_flops or float('nan'), syrk_launched)}
     out = {
         'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
         'value': world * args.steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -398,15 +421,20 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
                              'sum of the product launches per step; peak is the FULL chip although the launches only get '
                              'cus_available_to_kernel CUs when pipelined (the rest runs the Cholesky panel chain concurrently)',
                      'peak_source': 'datasheet fp64 matrix rate; v_mfma_f64_16x16x4_f64 issue-rate ubench on this chip ~74'},
-        'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble_kernel<elliptic>', 'achieved': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
-                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              'bytes_per_launch': 8.0 * N * N},
+        'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble2_kernel<elliptic> (the Gram evaluator launch itself)',
+                              'achieved': 8.0 * N * N / (asm_kernel_ms * 1e-3) / 1e9,
+                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'bytes_per_launch': 8.0 * N * N, 'kernel_ms': asm_kernel_ms,
+                              'call_ms': asm_ms, 'call_gbs': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
+                              'note': 'achieved = 8 N^2 bytes written / duration of the evaluator launch (HIP events around that launch on its '
+                                      'stream); call_ms = the whole gpk_assemble call (point packing kernel + launch overheads) by events around the call'},
         # the factorisation of Theta (north star: "MFMA fp64 utilisation for the factorisation"): N^3/3 flops are what a Cholesky
         # executes (nothing structural to skip) over the whole gpk_potrf call -- panel kernels, rank-64 updates and the trailing
         # GEMM updates together, HIP events on the handle's stream
         'roofline_cholesky_theta': {'bound': 'mfma', 'kernel': 'gpk_potrf(Theta): potrf_panel_mfma_kernel chain + gemm_k64_kernel + gemm_f64_kernel<NT> trailing updates',
                                     'achieved': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 'flops': N ** 3 / 3.0, 'ms': chol_ms},
+        'flops_counted_by_library': counted,
         'step_executed': {'flops_per_step': (trsm_flops or 0.0) + syrk_flops + (nz + 1) ** 3 / 3.0,
                           'tflops': ((trsm_flops or 0.0) + syrk_flops + (nz + 1) ** 3 / 3.0) * args.steps / elapsed / 1e12,
                           'frac_of_peak': ((trsm_flops or 0.0) + syrk_flops + (nz + 1) ** 3 / 3.0) * args.steps / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
@@ -417,9 +445,10 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     if not args.no_structured and world == 1 and not secondary:
         out['structured_step'] = structured_step(args, ctx, gpk, prob, T, Nd, Nb, f, g, z0, sol, Xd)
     if not args.no_cpu_baseline and world == 1:
-        out['cpu_baseline'] = cpu_baseline(T, N, Nd, Nb, f, g, z0)
-        out['cpu_baseline']['gpu_speedup_vs_reference_sequence'] = out['cpu_baseline']['seconds_per_step'] / (elapsed / args.steps)
-        out['cpu_baseline']['gpu_speedup_vs_triangular_best_cpu'] = out['cpu_baseline']['triangular_seconds_per_step'] / (elapsed / args.steps)
+        from oracle import gp_oracle as O
+        L = tril_inplace(T.download())
+        attach_cpu_baseline(out, O.EllipticSystem(ALPHA, M_EXP, f, g), [L], z0, f'N={N}, n_z={Nd}', dev_first, elapsed / args.steps)
+        del L
     ctx.close()
     return out if rank == 0 else None
 
@@ -457,58 +486,293 @@ def structured_step(args, ctx, gpk, prob, T, Nd, Nb, f, g, z0, sol_default, Xd):
     return out
 
 
-def cpu_baseline(T, N, Nd, Nb, f, g, z0):
-    """The CPU oracle on this box's host cores, full workload size, ONE Gauss-Newton step:
+def host_mem_available_gb():
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable:'):
+                return int(line.split()[1]) / 1048576.0
+    except Exception:                                             # noqa: BLE001
+        pass
+    return 0.0
+
+
+def tril_inplace(a):
+    """zero the strict upper triangle of a square host array without a second copy (9.2 GB at BASELINE config 5)"""
+    n = a.shape[0]
+    for i0 in range(0, n, 2048):
+        i1 = min(i0 + 2048, n)
+        a[i0:i1, i1:] = 0.0
+        a[i0:i1, i0:i1] = np.tril(a[i0:i1, i0:i1])
+    return a
+
+
+def cpu_baseline(sysm, Ls, z0, sample, dev=None, with_b1=True, with_mkl=True):
+    """The CPU oracle on this box's host cores, full workload size, ONE Gauss-Newton step from the benchmark's start z0 on the
+    DEVICE's factor(s) Ls (downloaded):
     B1 = the reference's operation sequence (general LU solves of the triangular L for Hessian, gradient and loss, LU
-    solve of H: src/PDEs.py:86,97,118) -- the stand-in for 'reference JAX on CPU', which cannot be installed here;
+    solve of H: src/PDEs.py:86,97,118,295-307, src/InverseProblems.py:126-166) -- the stand-in for 'reference JAX on CPU', which
+    cannot be installed here;
     B2 = the triangular formulation the GPU path uses (TRSM + SYRK + Cholesky of H), timed twice: on numpy/scipy (OpenBLAS)
-    and on torch CPU (MKL, SURVEY 8d "prefer MKL via torch"); the faster one is reported as the triangular figure."""
+    and on torch CPU (MKL, SURVEY 8d "prefer MKL via torch"); the faster one is reported as the triangular figure.
+    dev = (z1, loss0, loss1) of the device for the same step: the iterates the oracle computes ANYWAY are compared with it and
+    reported as `parity` (round 4; they used to be thrown away) -- relative deviation of the first iterate from B2 and from B1,
+    of the loss at the start and after the step; `ok` = iterate deviations <= 1e-6 (the north star's bound)."""
     from oracle import gp_oracle as O
-    L = np.tril(T.download())
-    sysm = O.EllipticSystem(ALPHA, M_EXP, f, g)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
+    t_b1 = z1_b1 = None
+    if with_b1:
+        t0 = time.perf_counter()
+        H, grad = O.gn_quantities(sysm, Ls, z0, faithful=True)
+        z1_b1 = z0 - np.linalg.solve(H, grad)
+        O.loss(sysm, Ls, z1_b1, faithful=True)
+        t_b1 = time.perf_counter() - t0
+        del H
     t0 = time.perf_counter()
-    H, grad = O.gn_quantities(sysm, [L], z0, faithful=True)
-    z1 = z0 - np.linalg.solve(H, grad)
-    O.loss(sysm, [L], z1, faithful=True)
-    t_b1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    O.gn_method(sysm, [L], z0, 1, 1, faithful=False)
+    z1_b2, hist_b2 = O.gn_method(sysm, Ls, z0, 1, 1, faithful=False)
     t_b2_np = time.perf_counter() - t0
     t_b2_mkl, mkl_threads, mkl_err = None, None, None
-    try:
-        import torch
-        mkl_threads = torch.get_num_threads()
-        Lt = torch.from_numpy(L)
-        def mkl_step():
-            A = torch.from_numpy(np.ascontiguousarray(sysm.A(z0)[0])); F = torch.from_numpy(np.ascontiguousarray(sysm.F(z0)[0]))
-            S = torch.linalg.solve_triangular(Lt, torch.cat([A, F[:, None]], dim=1), upper=False)
-            Hb = S.T @ S
-            Lh = torch.linalg.cholesky(Hb[:Nd, :Nd])
-            d = torch.cholesky_solve(Hb[:Nd, Nd:Nd + 1], Lh)
-            z1 = torch.from_numpy(z0) - d[:, 0]
-            w = torch.linalg.solve_triangular(Lt, torch.from_numpy(np.ascontiguousarray(sysm.F(z1.numpy())[0]))[:, None], upper=False)
-            return float((w * w).sum())
-        t0 = time.perf_counter()
-        mkl_step()
-        t_b2_mkl = time.perf_counter() - t0
-    except Exception as e:                                        # noqa: BLE001 -- reported
-        mkl_err = f'{type(e).__name__}: {e}'
+    if with_mkl:
+        try:
+            import torch
+            mkl_threads = torch.get_num_threads()
+            Lt = [None if L is None else torch.from_numpy(L) for L in Ls]
+            nz = sysm.nz
+            def mkl_step():
+                Hb = None
+                for L, A, F in zip(Lt, sysm.A(z0), sysm.F(z0)):
+                    AF = torch.from_numpy(np.ascontiguousarray(np.concatenate([A, F[:, None]], axis=1)))
+                    S = AF if L is None else torch.linalg.solve_triangular(L, AF, upper=False)
+                    Hb = S.T @ S if Hb is None else Hb + S.T @ S
+                _, ge, he = sysm.extra(z0)
+                if ge is not None:                                # data misfit (Darcy): diagonal Hessian term and gradient, halved like Hb
+                    Hb[torch.arange(nz), torch.arange(nz)] += torch.from_numpy(0.5 * he)
+                    Hb[:nz, nz] += torch.from_numpy(0.5 * ge)
+                Lh = torch.linalg.cholesky(Hb[:nz, :nz])
+                d = torch.cholesky_solve(Hb[:nz, nz:nz + 1], Lh)
+                z1 = z0 - d[:, 0].numpy()
+                tot = sysm.extra(z1)[0]
+                for L, F in zip(Lt, sysm.F(z1)):
+                    w = torch.from_numpy(np.ascontiguousarray(F))[:, None]
+                    if L is not None:
+                        w = torch.linalg.solve_triangular(L, w, upper=False)
+                    tot += float((w * w).sum())
+                return tot
+            t0 = time.perf_counter()
+            mkl_step()
+            t_b2_mkl = time.perf_counter() - t0
+        except Exception as e:                                    # noqa: BLE001 -- reported
+            mkl_err = f'{type(e).__name__}: {e}'
     t_b2 = min(t for t in (t_b2_np, t_b2_mkl) if t is not None)
     try:
         import threadpoolctl
         threads = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
     except Exception:
         threads = os.cpu_count()
-    return {'value': 1.0 / t_b1, 'unit': 'GN steps/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 Gauss-Newton step at the full workload size (N={N}, n_z={Nd}), reference operation sequence '
-                      f'(3 general LU solves of L + LU solve of H) with numpy/scipy BLAS; factor L taken from the device',
-            'seconds_per_step': t_b1, 'triangular_formulation_value': 1.0 / t_b2, 'triangular_seconds_per_step': t_b2,
-            'triangular_seconds_per_step_openblas': t_b2_np, 'triangular_seconds_per_step_torch_mkl': t_b2_mkl,
-            'torch_threads': mkl_threads, 'torch_mkl_error': mkl_err, 'host_cpus': os.cpu_count()}
+    parity = None
+    if dev is not None:
+        z1_dev, loss0_dev, loss1_dev = dev
+        parity = {'z1_rel_dev_vs_B2': rel(z1_dev, z1_b2), 'z1_rel_dev_vs_B1': rel(z1_dev, z1_b1) if z1_b1 is not None else None,
+                  'loss0_rel_dev': abs(loss0_dev / hist_b2[0] - 1.0), 'loss1_rel_dev': abs(loss1_dev / hist_b2[1] - 1.0),
+                  'loss0_device': loss0_dev, 'loss0_oracle': hist_b2[0], 'loss1_device': loss1_dev, 'loss1_oracle': hist_b2[1],
+                  'tol': PARITY_TOL,
+                  'what': 'first Gauss-Newton iterate z1 from the seeded N(0,1) start z0, device (gpk_gn_step) vs the CPU oracle on the '
+                          "device's factor: B2 = triangular formulation, B1 = reference operation sequence (LU solves); relative 2-norm "
+                          'deviations; loss0 / loss1 = loss at z0 / z1 (device: in-step value / gpk_gn_loss)'}
+        devs = [parity['z1_rel_dev_vs_B2']] + ([parity['z1_rel_dev_vs_B1']] if z1_b1 is not None else [])
+        parity['ok'] = bool(all(np.isfinite(d) and d <= PARITY_TOL for d in devs))
+    out = {'value': 1.0 / (t_b1 if t_b1 is not None else t_b2), 'unit': 'GN steps/s', 'cores': threads, 'kind': 'port',
+           'sample': f'1 Gauss-Newton step at the full workload size ({sample}), '
+                     + ('reference operation sequence (general LU solves of L for Hessian, gradient and loss + LU solve of H)' if with_b1 else
+                        'triangular formulation only (the reference operation sequence would take minutes at this size)')
+                     + ' with numpy/scipy BLAS; factor L taken from the device',
+           'seconds_per_step': t_b1 if t_b1 is not None else t_b2, 'reference_sequence_timed': bool(with_b1),
+           'triangular_formulation_value': 1.0 / t_b2, 'triangular_seconds_per_step': t_b2,
+           'triangular_seconds_per_step_openblas': t_b2_np, 'triangular_seconds_per_step_torch_mkl': t_b2_mkl,
+           'torch_threads': mkl_threads, 'torch_mkl_error': mkl_err, 'host_cpus': os.cpu_count()}
+    return out, parity
+
+
+def attach_cpu_baseline(out, sysm, Ls, z0, sample, dev, sec_per_step, **kw):
+    cb, parity = cpu_baseline(sysm, Ls, z0, sample, dev, **kw)
+    cb['gpu_speedup_vs_reference_sequence'] = cb['seconds_per_step'] / sec_per_step if cb['reference_sequence_timed'] else None
+    cb['gpu_speedup_vs_triangular_best_cpu'] = cb['triangular_seconds_per_step'] / sec_per_step
+    out['cpu_baseline'] = cb
+    out['parity'] = parity
+
+
+def first_step_on_device(ctx, prob, z0):
+    """(z1, loss at z0 as the step reports it, loss at z1 by gpk_gn_loss) of ONE Gauss-Newton step from z0 -- the device half of `parity`"""
+    zp = ctx.array(z0)
+    loss0, info = ctx.gn_step(prob, zp)
+    z1 = zp.download()
+    loss1 = ctx.gn_loss(prob, zp)
+    zp.free()
+    return z1, loss0, loss1
+
+
+# ------------------------------------------------------------------------------------------------------ configs 3 and 4
+def system_problem(workload):
+    """The reference drivers' own set-up of BASELINE configs 3 and 4 (main_Burgers1d.py:27-60, main_DarcyFlow2d.py:56-100 of the
+    reference): seed, sampler draw order, N(0,1) initial guess; for Darcy the observations come from the finite-difference truth."""
+    from src.sample_points import sampled_pts_rdm
+    Nd0, Nb0, gn_steps, desc = WORKLOADS[workload]
+    if workload == 'c3':
+        import main_Burgers1d as drv
+        np.random.seed(0)
+        Xd, Xb = sampled_pts_rdm(Nd0, Nb0, np.array(drv.SPACE_TIME), time_dependent=True)
+        z0 = np.random.normal(0.0, 1.0, 3 * Xd.shape[0])
+        truth = drv.cole_hopf_truth(0.02)
+        Xt = _grid(60, *drv.SPACE_TIME)
+        return dict(system='Burgers', layouts=['Burgers'], kernel='anisotropic_Gaussian', kp=[0.3, 0.05], nugget=1e-5, Xd=Xd, Xb=Xb,
+                    z0=z0, f=np.zeros(Xd.shape[0]), g=drv.initial_and_lateral(Xb[:, 0], Xb[:, 1]), p0=1.0, p1=0.02, data=None,
+                    Xt=Xt, truth_pts=truth(Xd[:, 0], Xd[:, 1]), truth_test=truth(Xt[:, 0], Xt[:, 1]), desc=desc, gn_steps=gn_steps)
+    import main_DarcyFlow2d as drv
+    from scipy.interpolate import griddata
+    from reference_solver.FD_for_Darcy_flow import FD_Darcy_flow_2d
+    np.random.seed(9999)
+    Xd, Xb = sampled_pts_rdm(Nd0, Nb0, np.array(drv.UNIT_SQUARE))
+    ndata, noise = 60, 1e-3
+    u_grid = FD_Darcy_flow_2d(drv.GRID - 2, drv.permeability, drv.source)
+    xx = np.linspace(0, 1, drv.GRID)
+    XX, YY = np.meshgrid(xx, xx)
+    obs = griddata((XX.flatten(), YY.flatten()), u_grid.reshape(-1, 1), (Xd[:ndata, 0], Xd[:ndata, 1]), method='linear')[:, 0]
+    data = obs + noise * np.random.normal(0, 1.0, ndata)          # Darcy_flow2d.get_observation, src/InverseProblems.py:60-64 of the reference
+    z0 = np.random.normal(0.0, 1.0, 6 * Nd0)
+    Xt = np.concatenate((XX.reshape(-1, 1), YY.reshape(-1, 1)), axis=1)
+    return dict(system='Darcy_flow2d', layouts=['Darcy_u', 'Darcy_a'], kernel='Gaussian', kp=SIGMA, nugget=1e-8, Xd=Xd, Xb=Xb, z0=z0,
+                f=np.ones(Nd0), g=np.zeros(Xb.shape[0]), p0=noise, p1=0.0, data=data, Xt=Xt, truth_pts=None,
+                truth_test=u_grid.reshape(-1), truth_a=drv.permeability(Xt[:, 0], Xt[:, 1]), desc=desc, gn_steps=gn_steps)
+
+
+def _grid(n, r1, r2):
+    XX, YY = np.meshgrid(np.linspace(r1[0], r1[1], n), np.linspace(r2[0], r2[1], n))
+    return np.concatenate((XX.reshape(-1, 1), YY.reshape(-1, 1)), axis=1)
+
+
+def run_system(args, workload, steps=None, warmup=None):
+    """BASELINE config 3 (Burgers) or 4 (Darcy) on one GPU under the same clock as the primary workload: K timed Gauss-Newton steps
+    after W warm-up steps from the seeded start, per-phase times and executed flops from the library's own counters, L2 errors
+    against the Cole-Hopf / finite-difference truths, CPU baselines B1 / B2 and the `parity` object.  Past convergence (8 steps) a
+    step still does exactly the same work: nothing in it depends on the size of the update."""
+    import torch
+    import gpk
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    torch.cuda.set_device(0)
+    ctx = gpk.Context(0)
+    P = system_problem(workload)
+    Xd, Xb, z0 = P['Xd'], P['Xb'], P['z0']
+    Nd, Nb = Xd.shape[0], Xb.shape[0]
+    factors, one_time, asm_bytes, asm_kernel_s = [], {}, 0.0, 0.0
+    for lay in P['layouts']:
+        ctx.prof_enable(True)
+        T = None
+        for rep in range(2):
+            ctx.timer_start()
+            T, _ = ctx.assemble(lay, P['kernel'], P['kp'], Xd, Xb, P['nugget'], 'adaptive', out=T)
+            call_ms = ctx.timer_stop()                            # (includes the upload of the points: host arrays here)
+            k_ms = ctx.prof_read_assembly()
+        ctx.prof_enable(False)
+        n = T.rows
+        ctx.timer_start(); info = ctx.potrf(T); first_ms = ctx.timer_stop()
+        ctx.assemble(lay, P['kernel'], P['kp'], Xd, Xb, P['nugget'], 'adaptive', out=T)
+        ctx.timer_start(); info = ctx.potrf(T); chol_ms = ctx.timer_stop()
+        if info != 0:
+            raise RuntimeError(f'{workload}: Cholesky of the {lay} Gram matrix failed (info {info}) at the reference nugget')
+        one_time[lay] = {'order': n, 'assembly_kernel_ms': k_ms, 'assembly_call_ms': call_ms, 'assembly_gbs': 8.0 * n * n / (k_ms * 1e-3) / 1e9,
+                         'cholesky_ms': chol_ms, 'cholesky_first_call_ms': first_ms, 'cholesky_tflops': n ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12}
+        asm_bytes += 8.0 * n * n; asm_kernel_s += k_ms * 1e-3
+        factors.append(T)
+    ctx.synchronize(); t0 = time.perf_counter()
+    prob = gpk.GNProblem(ctx, P['system'], Nd, Nb, P['f'], P['g'], factors[0], p0=P['p0'], p1=P['p1'], data_u=P['data'],
+                         L2=factors[1] if len(factors) > 1 else None)
+    ctx.synchronize(); dinv_ms = 1e3 * (time.perf_counter() - t0)
+    nz, rows = prob.nz, prob.rows
+    prob.workspace()
+    dev_first = first_step_on_device(ctx, prob, z0)
+    z = ctx.array(z0)
+    losses = []
+    for _ in range(warmup):
+        losses.append(ctx.gn_step(prob, z)[0])
+    ctx.prof_enable(True)
+    ctx.synchronize(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses.append(ctx.gn_step(prob, z)[0])
+    ctx.synchronize(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    losses.append(ctx.gn_loss(prob, z))
+    n = max(prof['steps'], 1)
+    sol = z.download()
+    # ---- accuracy against the independent truths (the drivers' test grids)
+    meas = ctx.gn_measurement(prob, z)                            # [sol_vec_a (Darcy) | sol_vec]: the right-hand side of the extension
+    err = {}
+    if workload == 'c3':
+        coeff = ctx.array(meas[:4 * Nd + Nb]); ctx.potrs(factors[0], coeff, nrhs=1)
+        ext = ctx.extend('Burgers', P['kernel'], P['kp'], P['Xt'], Xd, Xb, coeff).download()
+        err = {'pts_L2_err': float(np.sqrt(np.mean((sol[:Nd] - P['truth_pts']) ** 2))),
+               'test_L2_err': float(np.sqrt(np.mean((ext - P['truth_test']) ** 2))), 'truth': 'Cole-Hopf transform, 80-node Gauss-Hermite quadrature'}
+    else:
+        cu = ctx.array(meas[3 * Nd:7 * Nd + Nb]); ctx.potrs(factors[0], cu, nrhs=1)
+        ca = ctx.array(meas[:3 * Nd]); ctx.potrs(factors[1], ca, nrhs=1)
+        eu = ctx.extend('Darcy_u', P['kernel'], P['kp'], P['Xt'], Xd, Xb, cu).download()
+        ea = ctx.extend('Darcy_a', P['kernel'], P['kp'], P['Xt'], Xd, Xb, ca).download()
+        err = {'u_test_L2_err': float(np.sqrt(np.mean((eu - P['truth_test']) ** 2))),
+               'a_test_L2_err': float(np.sqrt(np.mean((np.exp(ea) - P['truth_a']) ** 2))),
+               'data_misfit_rms': float(np.sqrt(np.mean((sol[3 * Nd:3 * Nd + 60] - P['data']) ** 2))),
+               'truth': 'flux-form finite differences on the 80 x 80 grid of the driver'}
+    solve_ms, phase_ms, prod_ms, tail_ms = prof['trsm_ms'] / n, prof['syrk_ms'] / n, prof['syrk_launch_ms'] / n, prof['trsv_update_ms'] / n
+    solve_fl, prod_fl, upd_fl = prof['solve_flops'] / n, prof['product_flops'] / n, prof['potrf_update_flops'] / n
+    chol_fl = (nz + 1) ** 3 / 3.0
+    dense = sum(float(T.rows) ** 2 * (nz + 1) for T in factors) + float(rows) * (nz + 1) ** 2 + chol_fl   # F1 of SURVEY 8d for this system
+    executed = solve_fl + prod_fl + chol_fl
+    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
+    out = {'value': steps / elapsed, 'unit': 'GN steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * elapsed / steps,
+           'config': {'workload': P['desc'], 'N_domain': Nd, 'N_boundary': Nb, 'theta_orders': [T.rows for T in factors], 'unknowns': nz,
+                      'stacked_rows': rows, 'kernel': P['kernel'], 'kernel_parameter': P['kp'], 'nugget': P['nugget'], 'nugget_type': 'adaptive',
+                      'reference_gn_steps': P['gn_steps'],
+                      'schedule': ('leading-zero layout (unknowns interleaved by collocation point: staircase of slope 1/3)' if workload == 'c3' else
+                                   'Darcy: two factors + data rows stacked; ' + os.environ.get('GPK_BENCH_DARCY_NOTE', 'see DESIGN section 4'))},
+           'l2_error': dict(err, gn_steps_run=warmup + steps, loss_first=losses[0], loss_last=losses[-1]),
+           'f1_tflops': dense * steps / elapsed / 1e12,
+           'phases_ms_per_step': {'trsm': solve_ms, 'syrk_and_potrf_H': phase_ms, 'syrk_launches_sum': prod_ms, 'trsv_update': tail_ms,
+                                  'pipelined': bool(prof['pipelined'])},
+           'one_time_ms': dict(one_time, diagonal_block_inverses=dinv_ms, diagonal_block_rows=prob.struct.dinv_block),
+           'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<.., NN> = the solve phase S = L^{-1}[A | F] of every factor',
+                        'achieved': tf(solve_fl, solve_ms), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(solve_fl, solve_ms) / FP64_MFMA_PEAK_TFLOPS,
+                        'traffic': stored_pmc_traffic('trsm_gemm', workload)[0], 'traffic_source': stored_pmc_traffic('trsm_gemm', workload)[1],
+                        'flops_per_step': solve_fl, 'launches_per_step': prof['solve_launches'] / n, 'phase_ms_per_step': solve_ms,
+                        'avg_launch_ms': solve_ms / max(prof['solve_launches'] / n, 1),
+                        'note': 'flops EXECUTED, counted by the launch logic (gpk_prof_read_flops) / phase time from HIP events inside the timed steps'},
+           'roofline_syrk': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<TN> = the product Hb = S^T S', 'achieved': tf(prod_fl, prod_ms),
+                             'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(prod_fl, prod_ms) / FP64_MFMA_PEAK_TFLOPS,
+                             'traffic': stored_pmc_traffic('syrk', workload)[0], 'flops_per_step': prod_fl,
+                             'launches_per_step': prof['product_launches'] / n, 'avg_launch_ms': prod_ms,
+                             'note': 'LAUNCHED flops of the product (lower tiles; when pipelined also the upper halves of the diagonal 512-blocks) / sum of its launches'},
+           'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble kernels of this system', 'achieved': asm_bytes / asm_kernel_s / 1e9,
+                                 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': asm_bytes / asm_kernel_s / 1e9 / HBM_PEAK_GBS, 'bytes': asm_bytes},
+           'step_executed': {'flops_per_step': executed, 'tflops': executed * steps / elapsed / 1e12,
+                             'frac_of_peak': executed * steps / elapsed / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                             'cholesky_H_update_flops_counted': upd_fl,
+                             'note': 'solve + product (counted) + (n_z+1)^3/3 for the Cholesky of H, over wall time per step'}}
+    if not args.no_cpu_baseline:
+        from oracle import gp_oracle as O
+        Ls = [tril_inplace(T.download()) for T in factors]
+        if workload == 'c3':
+            sysm, Ls_o = O.BurgersSystem(P['p0'], P['p1'], P['f'], P['g']), Ls
+        else:
+            sysm, Ls_o = O.DarcySystem(P['f'], P['g'], P['data'], P['p0']), [Ls[1], Ls[0]]   # oracle order: [L_a, L_u]
+        attach_cpu_baseline(out, sysm, Ls_o, z0, f'orders {[T.rows for T in factors]}, n_z={nz}', dev_first, elapsed / steps)
+    ctx.close()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------ sharded
-def run_sharded(args, workload, steps=None, warmup=None):
+def run_sharded(args, workload, steps=None, warmup=None, solo=False):
+    """solo: this process alone (world 1, no collective, whatever the job's size) -- the 1-GPU point of the strong-scaling series,
+    measured by rank 0 inside a multi-rank job while the other ranks wait"""
     import torch
     import torch.distributed as dist
     import gpk
@@ -517,8 +781,8 @@ def run_sharded(args, workload, steps=None, warmup=None):
 
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
+    world = 1 if solo else int(os.environ.get('WORLD_SIZE', '1'))
+    rank = 0 if solo else int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -527,6 +791,8 @@ def run_sharded(args, workload, steps=None, warmup=None):
     ctx = gpk.Context(local)
     ops = GpuBlockOps(ctx)                                        # libgpk now runs on torch's current stream
     comm = Comm()
+    if solo:
+        comm.on, comm.rank, comm.world = False, 0, 1
     solver = ShardedFactorSolve(ops, comm, nb=args.panel)
     # Two executors of the same schedule (the plan of gpk_mg_plan_potrf): 'native' (default) = gpk_mg_* behind the C ABI, HIP streams
     # and events, RCCL called from C on a communicator of its own (unique id shipped through the process group); 'python' =
@@ -584,18 +850,26 @@ def run_sharded(args, workload, steps=None, warmup=None):
         if info == 0 or nugget >= 1e-8:
             break
         nugget *= 10.0
+    chol_first_ms = chol_ms                                       # (first factorisation of the process: code objects, buffers)
+    if world == 1:
+        _, chol_ms, _ = factor_once()
     if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1':
         # More than one rank: the factorisation is timed with BOTH plans -- look-ahead (default) and the strictly sequential
         # factor -> broadcast -> update -- and the faster one (max over ranks, so every rank decides alike) is kept for what
         # follows; both times are reported.  (Look-ahead hides broadcasts behind updates but its panel kernels share the CUs
         # with the update GEMMs of the same GPU; which effect wins depends on the fabric.)
-        mode_probe['cholesky_theta_ms'] = {'lookahead': chol_ms}
-        set_mode(lookahead=0)
-        _, c2, info2 = factor_once()
-        mode_probe['cholesky_theta_ms']['sequential'] = c2
-        if c2 < chol_ms and info2 == info:
+        # (the factorisation above was the first of the process -- side streams, events, transfer buffers, the first broadcast -- and
+        # is reported as one_time_ms.cholesky_theta_first_call; both plans are timed WARM here: one untimed run of the sequential plan,
+        # then look-ahead and sequential once each)
+        chol_first_ms = chol_ms
+        set_mode(lookahead=0); factor_once()
+        set_mode(lookahead=1); _, c1, info1 = factor_once()
+        set_mode(lookahead=0); _, c2, info2 = factor_once()
+        mode_probe['cholesky_theta_ms'] = {'lookahead': c1, 'sequential': c2, 'first_call_lookahead': chol_first_ms}
+        if c2 < c1 and info2 == info:
             chol_ms = c2
         else:
+            chol_ms = c1
             set_mode(lookahead=1)
         mode_probe['lookahead_kept'] = bool(solver.lookahead)
     ps = GNProblemStruct()
@@ -618,12 +892,20 @@ def run_sharded(args, workload, steps=None, warmup=None):
         step = lambda: mgpu.gn_step(ps, z.data_ptr(), 1.0, S.data_ptr(), lds, S2.data_ptr(), Hb.data_ptr(), lds, delta.data_ptr())[0]
     else:
         step = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
+    # first step from z0 for `parity` (every rank takes part: the step is collective; it is also the untimed first step that pays
+    # the one-time allocations of the executor); the iterate is then reset to z0
+    loss0_dev = step()
+    z1_dev = z.cpu().numpy().copy()
+    w1 = t(np.concatenate([ALPHA * z1_dev ** M_EXP - f, z1_dev, g]))          # F(z1), src/PDEs.py:84-85 of the reference
+    ops.trsv(Theta, N, w1, False)                                 # loss(z1) = || L^{-1} F(z1) ||^2 by true substitution
+    loss1_dev = float((w1 * w1).sum().item())
+    z.copy_(t(z0))
     losses = []
     if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1':
         # the same for the Cholesky of the bordered Gauss-Newton matrix: one untimed-for-the-metric step each with the replicated
         # and with the panel-sharded factorisation, the faster one kept (all ranks alike); these two steps count as warm-up
         times = {}
-        for name, flag in (('replicated', 0), ('panel_sharded', 1)):
+        for name, flag in (('replicated', 0), ('panel_sharded', 1), ('replicated', 0), ('panel_sharded', 1)):   # A/B/A/B: the first pair warms both up
             set_mode(shard_hb=flag)
             comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
             losses.append(step())
@@ -632,7 +914,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
         set_mode(shard_hb=int(times['panel_sharded'] < times['replicated']))
         mode_probe['step_ms_by_cholesky_of_Hb'] = times
         mode_probe['shard_hb_kept'] = bool(solver.shard_hb)
-        warmup_run = 2
+        warmup_run = 4
     else:
         for _ in range(warmup):
             losses.append(step())
@@ -689,7 +971,7 @@ def run_sharded(args, workload, steps=None, warmup=None):
             'l2_error': {'pts_L2_err': pts_l2, 'test_L2_err': test_l2, 'gn_steps_run': warmup_run + steps,
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
             'f1_tflops': rate,
-            'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'diagonal_block_inverses': dinv_ms},
+            'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'cholesky_theta_first_call': chol_first_ms, 'diagonal_block_inverses': dinv_ms},
             'mode_probe': mode_probe or None,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step: solve + product + Cholesky of Hb), flops EXECUTED summed over the ranks',
                          'achieved': ex_rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
@@ -699,8 +981,19 @@ def run_sharded(args, workload, steps=None, warmup=None):
             'roofline_cholesky_theta': {'bound': 'mfma', 'kernel': 'sharded Cholesky of Theta (panel kernels + trailing GEMM updates; broadcasts at N > 1)',
                                         'achieved': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
                                         'frac': N ** 3 / 3.0 / (chol_ms * 1e-3) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world), 'ms': chol_ms},
-            'cpu_baseline': None,
+            'cpu_baseline': None, 'parity': None,
         }
+        # CPU oracle on the device's factor (B2 only: the reference operation sequence needs minutes at order 34000), `parity` beside it
+        need_gb = 3.2 * 8.0 * N * N / 1e9 + 4.0 * 8.0 * N * (nz + 1) / 1e9
+        if not args.no_cpu_baseline and not args.no_sharded_parity:
+            if host_mem_available_gb() > need_gb + 16:
+                from oracle import gp_oracle as O
+                Lh = np.ascontiguousarray(tril_inplace(Theta.cpu().numpy()[:, :N]))
+                attach_cpu_baseline(out, O.EllipticSystem(ALPHA, M_EXP, f, g), [Lh], z0,
+                                    f'N={N}, n_z={nz}', (z1_dev, loss0_dev, loss1_dev), elapsed / steps, with_b1=False, with_mkl=False)
+                del Lh
+            else:
+                out['parity'] = {'skipped': f'host memory available {host_mem_available_gb():.0f} GB < {need_gb + 16:.0f} GB needed by the CPU oracle at this size'}
     if mgpu:
         mgpu.close()
     del S, S2, Hb, Theta, Dinv
@@ -714,12 +1007,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', choices=['auto', 'c1', 'c2', 'c5', 'n10k'], default='auto')
+    ap.add_argument('--workload', choices=['auto', 'c1', 'c2', 'c3', 'c4', 'c5', 'n10k'], default='auto')
     ap.add_argument('--panel', type=int, default=512, help='panel width of the sharded Cholesky')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-structured', action='store_true', help='skip the secondary measurement of the optional structured solve')
     ap.add_argument('--no-sharded-config', action='store_true', help='skip the BASELINE config 5 run reported under sharded_config')
     ap.add_argument('--no-n10k', action='store_true', help='skip the north-star target size (N_domain = 10000 on one GPU) reported under n10k')
+    ap.add_argument('--no-c3c4', action='store_true', help='skip BASELINE configs 3 (Burgers) and 4 (Darcy) reported under c3 / c4')
+    ap.add_argument('--no-sharded-parity', action='store_true', help='skip the CPU oracle step (about a minute, ~40 GB of host memory) behind sharded_config.parity')
+    ap.add_argument('--no-replicas', action='store_true', help='N > 1: skip the secondary measurement of N independent config-2 replicas')
     ap.add_argument('--sharded-path', action='store_true', help='use the multi-rank schedule for the primary workload')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -735,11 +1031,62 @@ def main():
         dist.init_process_group(os.environ.get('GPK_BENCH_BACKEND', 'nccl'))   # (gloo only in the CPU flow test)
         dist.barrier()                                            # creates the communicator NOW (RCCL prints its version banner to stdout
                                                                   # when it does: it must not come after the JSON line)
-    workload = args.workload if args.workload != 'auto' else 'c2'
     rank = int(os.environ.get('RANK', '0'))
-    if args.sharded_path or workload == 'c5':
-        out = run_sharded(args, workload)
+    SECONDARY_KEYS = ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'config', 'l2_error', 'f1_tflops', 'phases_ms_per_step',
+                      'one_time_ms', 'roofline', 'roofline_syrk', 'roofline_assembly', 'roofline_cholesky_theta', 'flops_counted_by_library',
+                      'step_executed', 'mode_probe', 'cpu_baseline', 'parity')
+    pick = lambda d: {k: d[k] for k in SECONDARY_KEYS if k in d}
+
+    def contract_line(obj, n_gpus, scaling):
+        """a run_system result dressed as the driver's line"""
+        return dict({'metric': 'Gauss-Newton steps/sec + L2 error at N_domain points', 'n_gpus': n_gpus, 'higher_is_better': True,
+                     'scaling': scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic'}, **obj)
+
+    if world > 1 and args.workload in ('auto', 'c5') and not args.sharded_path:
+        # ---- N > 1 ranks: `value` IS the sharded BASELINE config 5 (the north star's scaling series: fixed total work, strong scaling).
+        # The same job also times config 5 on rank 0 ALONE (vs_1gpu: a self-contained strong-scaling point per job) and, as a secondary
+        # object, N independent replicas of config 2 (what `value` used to be up to round 3).
+        # Order: the replicas first (no data-path collective: robust); their line is what survives if the sharded run fails or hangs
+        # (AbortWatch prints it with the error attached and `value` then IS the replica figure, labelled as such).
+        from gpk.sharded import Comm
+        import torch.distributed as dist
+        rep = None
+        if not args.no_replicas:
+            rep = run_single(args, 'c2', Comm())
+            if rep is not None:
+                rep['fallback'] = ('the sharded BASELINE config 5 run did not complete (see sharded_config.error): `value` is the aggregate of N '
+                                   'independent config-2 replicas, NOT the strong-scaling figure')
+        watch = AbortWatch(rank, rep, use_store=True)
+        solo = None
+        try:
+            out = run_sharded(args, 'c5')
+            if rank == 0:
+                try:
+                    solo = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1, solo=True)
+                except Exception as e:                            # noqa: BLE001 -- reported
+                    solo = {'error': f'{type(e).__name__}: {e}'}
+            dist.barrier()
+        except Exception as e:                                    # noqa: BLE001 -- reported, not swallowed
+            watch.fail(f'rank {rank}: {type(e).__name__}: {e}')   # does not return (peers may be blocked in a collective)
+        watch.stop()
+        if out is not None:
+            if solo and 'value' in solo:
+                out['one_gpu_same_job'] = pick(solo)
+                out['vs_1gpu'] = out['value'] / solo['value']
+                out['parallel_efficiency'] = out['vs_1gpu'] / world
+            else:
+                out['one_gpu_same_job'] = solo
+                out['vs_1gpu'] = None
+            out['scaling_series'] = ('BASELINE config 5, strong scaling: this line\'s `value` at n_gpus > 1; at n_gpus = 1 the default line reports config 2 as '
+                                     '`value` (the configuration the metric is quoted on, it fits one GPU) and config 5 on one GPU under `sharded_config`')
+            if rep is not None:
+                out['replicas_c2'] = {k: rep[k] for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'scaling', 'config', 'l2_error') if k in rep}
+    elif args.sharded_path or args.workload == 'c5':
+        out = run_sharded(args, args.workload if args.workload != 'auto' else 'c2')
+    elif args.workload in ('c3', 'c4'):
+        out = contract_line(run_system(args, args.workload), 1, 'weak')
     else:
+        workload = args.workload if args.workload != 'auto' else 'c2'
         from gpk.sharded import Comm
         out = run_single(args, workload, Comm() if world > 1 else None)
         if args.workload == 'auto' and world == 1 and not args.no_n10k:
@@ -747,19 +1094,21 @@ def main():
             # same line, its own CPU baselines beside it (B1 = reference operation sequence, ~1 min on the host cores; B2 = triangular)
             try:
                 nk = run_single(args, 'n10k', None, secondary=True, steps=min(args.steps, 4), warmup=1)
-                out['n10k'] = {k: nk[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'config', 'l2_error', 'f1_tflops',
-                                                   'phases_ms_per_step', 'one_time_ms', 'roofline', 'roofline_syrk', 'roofline_cholesky_theta',
-                                                   'step_executed', 'cpu_baseline') if k in nk}
+                out['n10k'] = pick(nk)
             except Exception as e:                                # noqa: BLE001 -- reported, the primary value survives
                 out['n10k'] = {'error': f'{type(e).__name__}: {e}'}
+        if args.workload == 'auto' and world == 1 and not args.no_c3c4:
+            for name in ('c3', 'c4'):                             # BASELINE configs 3 and 4 under the same clock
+                try:
+                    out[name] = run_system(args, name)
+                except Exception as e:                            # noqa: BLE001 -- reported, the primary value survives
+                    out[name] = {'error': f'{type(e).__name__}: {e}'}
         if args.workload == 'auto' and not args.no_sharded_config:
             watch = AbortWatch(rank, out, use_store=use_pg)
             try:                                                  # the value above must survive a failure of the secondary run
                 sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
                 if out is not None and sh is not None:
-                    out['sharded_config'] = {k: sh[k] for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling',
-                                                                 'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline',
-                                                                 'roofline_cholesky_theta', 'mode_probe') if k in sh}
+                    out['sharded_config'] = pick(sh)
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
                 msg = f'{type(e).__name__}: {e}'
                 if use_pg:
@@ -767,6 +1116,14 @@ def main():
                 if out is not None:
                     out['sharded_config'] = {'error': msg}
             watch.stop()
+    # parity is a gate, not a remark: any object of the line whose device iterate is further than 1e-6 from the oracle's fails the run
+    bad = []
+    if out is not None:
+        for key, obj in [('value', out)] + [(k, out.get(k)) for k in ('n10k', 'c3', 'c4', 'sharded_config', 'one_gpu_same_job')]:
+            par = obj.get('parity') if isinstance(obj, dict) else None
+            if isinstance(par, dict) and par.get('ok') is False:
+                bad.append(key)
+        out['parity_failed'] = bad or None
     # the ONE line goes out before anything that can still block (a peer that died after its last collective would otherwise
     # leave rank 0 in the final barrier with the result unprinted)
     if out is not None:
@@ -775,6 +1132,9 @@ def main():
         except Exception:                                         # noqa: BLE001
             pass
         print(json.dumps(out), flush=True)
+        if bad:
+            print(f'bench.py: PARITY FAILURE -- device iterate further than {PARITY_TOL:g} (relative) from the CPU oracle in: {", ".join(bad)}',
+                  file=sys.stderr, flush=True)
     if use_pg:
         import threading
         import torch.distributed as dist
@@ -782,6 +1142,8 @@ def main():
                          daemon=True).start()
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.exit(4)
 
 
 if __name__ == '__main__':

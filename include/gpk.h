@@ -68,6 +68,14 @@ int gpk_prof_read(gpk_handle h, double* host_ms4, int* host_count);
  * is 0.  *host_pipelined = 1 if the last step ran pipelined; *host_syrk_launch_ms = accumulated duration of the SYRK launches
  * themselves (HIP events on the stream they ran on); *host_chain_cus = CUs of the chain partition. */
 int gpk_prof_read_pipeline(gpk_handle h, int* host_pipelined, double* host_syrk_launch_ms, int* host_chain_cus);
+/* Flops EXECUTED by the matrix-product launches issued while the per-phase timing was on, accumulated per phase from the K ranges
+ * the launch logic gives its tiles (structural zeros of A(z), triangular operands and skipped upper tiles left out):
+ * host_flops4 = {solve S = L^{-1}[A | F], updates inside the factorisation of Hb, the product Hb = S^T S, unused};
+ * host_launches4 (may be NULL) = number of launches behind each figure.  The panel / substitution kernels are not counted. */
+int gpk_prof_read_flops(gpk_handle h, double* host_flops4, long* host_launches4);
+/* Duration of the Gram evaluator launch of the LAST gpk_assemble call issued while the per-phase timing was on (HIP events on the
+ * handle's stream around that launch alone; the point packing kernel and the host-side set-up stay outside).  Synchronises. */
+int gpk_prof_read_assembly(gpk_handle h, double* host_ms);
 
 /* ---- Gram assembly: replaces Gram_matrix_assembly (src/Gram_matrice.py:11-187) plus the nugget of
  *      *.Gram_matrix (src/PDEs.py:56-73,250-269,391-409; src/InverseProblems.py:66-99) in one fused pass.
@@ -86,6 +94,11 @@ int gpk_assemble_test(gpk_handle h, int layout, int kernel, const double* host_k
 int gpk_extend(gpk_handle h, int layout, int kernel, const double* host_kparams,
                const double* Xt, int Nt, const double* Xd, int Nd, const double* Xb, int Nb,
                const double* coeff, double* out);
+/* solver_GP.collocation_pts_err / get_test_error (src/solver.py:169-178, 185-194): err_all[i] = |truth[i] - approx[i]| (device, may be
+ * NULL), *host_max = max_i err_all[i], *host_l2 = sqrt(sum_i err_all[i]^2 / n) -- the reference's "L2 error".  All inputs on the
+ * device (the extension already is); one pass, fixed summation order.  Synchronises. */
+int gpk_error_metrics(gpk_handle h, int n, const double* truth, const double* approx, double* err_all,
+                      double* host_max, double* host_l2);
 
 /* ---- dense fp64 linear algebra on the MFMA units --------------------------------------------------------- */
 /* jnp.linalg.cholesky (src/PDEs.py:77,273,413; src/InverseProblems.py:102-103): lower factor in place (strict

@@ -51,6 +51,10 @@ int gpk_mg_destroy(gpk_mg_handle mg);                          /* also destroys 
 /* an existing communicator + the two collectives of the RCCL build that created it (or stand-ins) */
 int gpk_mg_set_comm(gpk_mg_handle mg, void* comm, gpk_mg_bcast_fn bcast, gpk_mg_allgather_fn allgather);
 /* librccl_path: NULL = "librccl.so.1" by the loader's search order.  host_id128: 128 bytes. */
+/* gpk_mg_rccl_probe: can this process load the library and find ncclGetUniqueId / ncclCommInitRank / ncclBroadcast /
+ * ncclAllGather?  No communicator, no GPU call -- so that all ranks can agree on the answer BEFORE any of them enters
+ * ncclCommInitRank (which blocks until every rank has arrived).  0 = yes; errbuf (may be NULL) receives the reason otherwise. */
+int gpk_mg_rccl_probe(const char* librccl_path, char* errbuf, int errbuf_cap);
 int gpk_mg_rccl_unique_id(const char* librccl_path, void* host_id128);
 int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* host_id128);
 /* key 0: look-ahead (0 off, 1 on; default on for world > 1);  key 1: Cholesky of Hb (0 replicated, 1 panel-sharded;

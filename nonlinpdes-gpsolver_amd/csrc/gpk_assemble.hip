@@ -306,6 +306,14 @@ extern "C" int gpk_assemble(gpk_handle h, int layout, int kernel, const double* 
     // two column points per lane (16-byte stores) when every pair (q, q + 1) stays inside one block and is 16-byte aligned
     bool pairs = g_asm_pairs && (ld % 2 == 0) && (((uintptr_t)Theta & 15) == 0) && (g.M % 2 == 0);
     for (int b = 0; b < nb; ++b) pairs = pairs && (g.off[b] % 2 == 0) && (g.size[b] % 2 == 0);
+    // (per-phase timing on: HIP events around the evaluator launch alone -- the point packing and the host work above stay outside)
+    if (h->prof) {
+        if (!h->asm_ev[0]) for (int i = 0; i < 2; ++i) GPK_HIP(h, hipEventCreate(&h->asm_ev[i]));
+        GPK_HIP(h, hipEventRecord(h->asm_ev[0], h->stream));
+    }
+    struct AsmStop {
+        gpk_handle h; ~AsmStop() { if (h->prof && h->asm_ev[1]) h->asm_timed = hipEventRecord(h->asm_ev[1], h->stream) == hipSuccess; }
+    } asm_stop{h};
     if (pairs) {
         dim3 grid2(gpk_ceil_div(g.M / 2, 256), gpk_ceil_div(g.M, TP));
         switch (layout) {
@@ -342,6 +350,45 @@ extern "C" int gpk_assemble_test(gpk_handle h, int layout, int kernel, const dou
         case GPK_LAYOUT_DARCY_A:  assemble_test_kernel<GPK_LAYOUT_DARCY_A><<<grid, 256, 0, h->stream>>>(g); break;
     }
     GPK_LAUNCH_CHECK(h);
+    return 0;
+}
+
+// err[i] = |truth[i] - approx[i]|, its maximum and its sum of squares in one pass (one workgroup: n is a point count, at most a
+// few 10^4; fixed summation order, so the figures are reproducible)
+__global__ __launch_bounds__(1024) void error_metrics_kernel(int n, const double* __restrict__ truth, const double* __restrict__ approx,
+                                                              double* __restrict__ err, double* __restrict__ out2) {
+    __shared__ double smax[16], ssum[16];
+    double m = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double e = fabs(truth[i] - approx[i]);
+        if (err) err[i] = e;
+        m = (e > m || e != e) ? e : m;                               // NaNs propagate, as under jnp.max
+        q = fma(e, e, q);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double mo = __shfl_down(m, off, 64);
+        m = (mo > m || mo != mo) ? mo : m;
+        q += __shfl_down(q, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = m; ssum[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mm = 0.0, qq = 0.0;
+        for (int w = 0; w < 16; ++w) { mm = (smax[w] > mm || smax[w] != smax[w]) ? smax[w] : mm; qq += ssum[w]; }
+        out2[0] = mm; out2[1] = qq;
+    }
+}
+
+extern "C" int gpk_error_metrics(gpk_handle h, int n, const double* truth, const double* approx, double* err_all,
+                                 double* host_max, double* host_l2) {
+    if (!h || !truth || !approx || n <= 0 || !host_max || !host_l2) return GPK_ERR_ARG;
+    error_metrics_kernel<<<1, 1024, 0, h->stream>>>(n, truth, approx, err_all, h->d_scalars + 2);
+    GPK_LAUNCH_CHECK(h);
+    double r[2] = {0.0, 0.0};
+    GPK_HIP(h, hipMemcpyAsync(r, h->d_scalars + 2, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipStreamSynchronize(h->stream));
+    *host_max = r[0];
+    *host_l2 = sqrt(r[1] / (double)n);
     return 0;
 }
 

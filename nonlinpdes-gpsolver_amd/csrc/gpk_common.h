@@ -68,6 +68,11 @@ struct gpk_ctx {
     hipEvent_t pev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double prof_ms[4] = {0, 0, 0, 0};
     int prof_cnt = 0;
+    hipEvent_t asm_ev[2] = {nullptr, nullptr};   // around the last gpk_assemble evaluator launch while prof is on (gpk_prof_read_assembly)
+    bool asm_timed = false;
+    int prof_phase = 0;             // phase the step is issuing right now (last GPK_PROF_MARK index): 0 solve, 1 product + factorisation of Hb, ...
+    double prof_flops[4] = {0, 0, 0, 0};   // flops EXECUTED by the GEMM launches of each phase while prof is on (gpk_gemm.hip, prof_count)
+    long prof_launches[4] = {0, 0, 0, 0};
     std::string err;
 };
 

@@ -77,6 +77,7 @@ extern "C" int gpk_destroy(gpk_handle h) {
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (int i = 0; i < 5; ++i) if (h->pev[i]) (void)hipEventDestroy(h->pev[i]);
+    for (int i = 0; i < 2; ++i) if (h->asm_ev[i]) (void)hipEventDestroy(h->asm_ev[i]);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return 0;
@@ -190,6 +191,27 @@ extern "C" int gpk_prof_enable(gpk_handle h, int on) {
     h->prof_cnt = 0;
     h->prof_syrk_ms = 0.0;
     h->prof_pipelined = 0;
+    h->prof_phase = 0;
+    for (int i = 0; i < 4; ++i) { h->prof_flops[i] = 0.0; h->prof_launches[i] = 0; }
+    return 0;
+}
+
+extern "C" int gpk_prof_read_assembly(gpk_handle h, double* host_ms) {
+    if (!h || !host_ms) return GPK_ERR_ARG;
+    if (!h->asm_timed) return gpk_bad_arg(h, "prof_read_assembly: no gpk_assemble call was timed (gpk_prof_enable first)");
+    GPK_HIP(h, hipEventSynchronize(h->asm_ev[1]));
+    float ms = 0.f;
+    GPK_HIP(h, hipEventElapsedTime(&ms, h->asm_ev[0], h->asm_ev[1]));
+    *host_ms = (double)ms;
+    return 0;
+}
+
+extern "C" int gpk_prof_read_flops(gpk_handle h, double* host_flops4, long* host_launches4) {
+    if (!h || !host_flops4) return GPK_ERR_ARG;
+    for (int i = 0; i < 4; ++i) {
+        host_flops4[i] = h->prof_flops[i];
+        if (host_launches4) host_launches4[i] = h->prof_launches[i];
+    }
     return 0;
 }
 

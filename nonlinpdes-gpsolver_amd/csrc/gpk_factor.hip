@@ -2237,7 +2237,11 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
             while (h->pipe_tev.size() < 2) { hipEvent_t e; GPK_HIP(h, hipEventCreate(&e)); h->pipe_tev.push_back(e); }
             GPK_HIP(h, hipEventRecord(h->pipe_tev[0], h->stream));
         }
-        GPK_TRY(gpk_i_gemm(h, true, false, nc, nc, rows, 1.0, W, ldw, W, ldw, 0.0, Hb, ldh, true, lead));
+        const int ph = h->prof_phase;
+        h->prof_phase = 2;                                           // (flop accounting: the product, apart from the factorisation's updates)
+        const int rcp = gpk_i_gemm(h, true, false, nc, nc, rows, 1.0, W, ldw, W, ldw, 0.0, Hb, ldh, true, lead);
+        h->prof_phase = ph;
+        GPK_TRY(rcp);
         if (h->prof) { GPK_HIP(h, hipEventRecord(h->pipe_tev[1], h->stream)); h->pipe_tev_used = 2; }
         if (d_loss) GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)(nc - 1) * ldh + (nc - 1), sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         return gpk_i_potrf(h, Hb, nc, ldh, 0);
@@ -2284,7 +2288,10 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
 #define PIPE_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
     auto timed_product = [&](hipStream_t s, int jb, int je) -> int {  // (HIP events around the launch: bench.py's roofline leg)
         if (h->prof) { hipError_t e = hipEventRecord(h->pipe_tev[ntev], s); if (e != hipSuccess) return fail(e, "hipEventRecord"); }
+        const int ph = h->prof_phase;
+        h->prof_phase = 2;                                           // (flop accounting: the product, apart from the factorisation's updates)
         const int r = product(jb, je);
+        h->prof_phase = ph;
         if (h->prof) {
             hipError_t e = hipEventRecord(h->pipe_tev[ntev + 1], s); if (e != hipSuccess) return fail(e, "hipEventRecord");
             ntev += 2; h->pipe_tev_used = ntev;

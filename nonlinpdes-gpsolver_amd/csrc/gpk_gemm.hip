@@ -613,8 +613,45 @@ __global__ __launch_bounds__(256, 2) void gemm_k64_kernel(GemmArgs g) {
         }
 }
 
+// Flops a launch EXECUTES, from the K ranges the kernel derives for its tiles (leading zeros, triangular operand, skipped upper
+// tiles; rows and columns past the edge of C not counted): accumulated per phase of the Gauss-Newton step while the per-phase
+// timing is on (gpk_prof_enable) and read back with gpk_prof_read_flops -- the numerator of bench.py's roofline legs, taken from
+// the launch logic itself instead of a host-side model of it.
+void prof_count(gpk_handle h, const GemmArgs& g, int BM, int BN) {
+    if (!h->prof) return;
+    const int ph = h->prof_phase < 0 ? 0 : h->prof_phase > 3 ? 3 : h->prof_phase;
+    double fl = 0.0;
+    const int ntm_full = g.tri_a ? g.ntm_full : g.ntm;
+    for (int tn = 0; tn < g.ntn; ++tn) {
+        const int n0 = tn * BN, bn = std::min(BN, g.N - n0);
+        int k0 = 0;
+        if (g.lead > 0) {
+            const int z = g.lead - (n0 + BN);
+            k0 = z > 0 ? ((z / g.lead_div) / BK) * BK : 0;
+        }
+        if (g.tri_a) {
+            for (int tm = 0; tm < ntm_full; ++tm) {
+                const int m0 = tm * BM, bm = std::min(BM, g.M - m0), kt = std::min(g.K, m0 + BM);
+                if (kt > k0) fl += 2.0 * bm * bn * (double)(kt - k0);
+            }
+            continue;
+        }
+        int mfirst = 0;                                              // first row that belongs to a computed tile of this column
+        if (g.lower_only) mfirst = n0;                               // (square tiles: row tile tn)
+        else if (g.skip_upper) mfirst = (n0 / BM) * BM;              // tiles with m0 + BM <= n0 are skipped
+        if (g.M > mfirst && g.K > k0) fl += 2.0 * (double)(g.M - mfirst) * bn * (double)(g.K - k0);
+    }
+    h->prof_flops[ph] += fl;
+    h->prof_launches[ph] += 1;
+}
+
 template <int BM>
 int launch_k64_bm(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
+    if (h->prof) {
+        const int ph = h->prof_phase < 0 ? 0 : h->prof_phase > 3 ? 3 : h->prof_phase;
+        h->prof_flops[ph] += 2.0 * g.M * (double)g.N * g.K;
+        h->prof_launches[ph] += 1;
+    }
     g.ntm = gpk_ceil_div(g.M, BM);
     g.ntn = gpk_ceil_div(g.N, 64);
     g.ntiles = g.ntm * g.ntn;
@@ -853,6 +890,7 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.ntn = gpk_ceil_div(g.N, BN);
     g.ntiles = g.lower_only ? g.ntm * (g.ntm + 1) / 2 : g.ntm * g.ntn;
     g.nsuper = 0;
+    prof_count(h, g, BM, BN);
     int nblocks = g.ntiles;
     if (g.lower_only && g.lead > 0 && g_supertile && g.lead_div == 1) {
         const int T = g.ntm, ncg = gpk_ceil_div(T, SG_W);

@@ -187,7 +187,7 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
 int g_use_dinv = 1;                  // gpk_debug_set key 10: 0 = substitution strips even when the inverses are supplied
 int g_eikonal_lz = 1;                // gpk_debug_set key 23: 0 = dense schedule for the Eikonal and Burgers systems
 
-#define GPK_PROF_MARK(h, i) do { if ((h)->prof) GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } while (0)
+#define GPK_PROF_MARK(h, i) do { if ((h)->prof) { (h)->prof_phase = (i); GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } } while (0)
 
 // S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered).
 // rev != 0 (elliptic system only): unknown j is stored in column nz-1-j; column c < nz of [A | F] is then zero above row

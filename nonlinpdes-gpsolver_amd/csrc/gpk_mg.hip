@@ -285,11 +285,21 @@ int gather_info(gpk_mg_handle mg, int* host_info) {
 
 struct nccl_unique_id { char internal[128]; };
 
-void* open_rccl(const char* path) {
+// dlerror() returns its message ONCE and clears it: read it right after the failing dlopen, before the next attempt resets it
+void* open_rccl(const char* path, std::string* err = nullptr) {
     void* lib = dlopen(path && path[0] ? path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!lib && !(path && path[0])) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        const char* e = dlerror();
+        if (err) *err = e ? e : "?";
+        if (!(path && path[0])) {
+            lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) { const char* e2 = dlerror(); if (err) *err += std::string("; ") + (e2 ? e2 : "?"); }
+        }
+    }
     return lib;
 }
+
+const char* const RCCL_SYMBOLS[] = {"ncclGetUniqueId", "ncclCommInitRank", "ncclBroadcast", "ncclAllGather"};
 
 }  // namespace
 
@@ -359,6 +369,20 @@ extern "C" int gpk_mg_set_option(gpk_mg_handle mg, int key, int value) {
     return gpk_bad_arg(mg->h, "gpk_mg_set_option: key / value");
 }
 
+// Can this process bind RCCL at all?  dlopen + the four entry points, nothing else (no communicator, no GPU call): lets every
+// rank AGREE on the answer (an all-reduce over the caller's process group) BEFORE any of them enters ncclCommInitRank, where a
+// rank whose peer never arrives would block.  errbuf (may be NULL) receives the reason.
+extern "C" int gpk_mg_rccl_probe(const char* librccl_path, char* errbuf, int cap) {
+    std::string err;
+    void* lib = open_rccl(librccl_path, &err);
+    if (lib) {
+        for (const char* sym : RCCL_SYMBOLS)
+            if (!dlsym(lib, sym)) { err = std::string(sym) + " not found in the library"; lib = nullptr; break; }
+    }
+    if (!lib && errbuf && cap > 0) snprintf(errbuf, (size_t)cap, "%s", err.c_str());
+    return lib ? 0 : GPK_ERR_NODEV;
+}
+
 extern "C" int gpk_mg_rccl_unique_id(const char* librccl_path, void* host_id128) {
     if (!host_id128) return GPK_ERR_ARG;
     void* lib = open_rccl(librccl_path);
@@ -372,8 +396,9 @@ extern "C" int gpk_mg_rccl_unique_id(const char* librccl_path, void* host_id128)
 extern "C" int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* host_id128) {
     if (!mg || !host_id128) return GPK_ERR_ARG;
     gpk_handle h = mg->h;
-    void* lib = open_rccl(librccl_path);
-    if (!lib) { h->err = std::string("gpk_mg_rccl_init: cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return GPK_ERR_NODEV; }
+    std::string lerr;
+    void* lib = open_rccl(librccl_path, &lerr);
+    if (!lib) { h->err = "gpk_mg_rccl_init: cannot load RCCL: " + lerr; return GPK_ERR_NODEV; }
     auto init = (int (*)(void**, int, nccl_unique_id, int))dlsym(lib, "ncclCommInitRank");
     auto bc = (gpk_mg_bcast_fn)dlsym(lib, "ncclBroadcast");
     auto ag = (gpk_mg_allgather_fn)dlsym(lib, "ncclAllGather");

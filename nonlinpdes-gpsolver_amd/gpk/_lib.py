@@ -33,6 +33,7 @@ PROTOTYPES = {
     'gpk_mg_create': (_i, [_vp, _i, _i, _i, _pvp]),
     'gpk_mg_destroy': (_i, [_vp]),
     'gpk_mg_set_comm': (_i, [_vp, _vp, MG_BCAST_FN, MG_ALLGATHER_FN]),
+    'gpk_mg_rccl_probe': (_i, [C.c_char_p, C.c_char_p, _i]),
     'gpk_mg_rccl_unique_id': (_i, [C.c_char_p, _vp]),
     'gpk_mg_rccl_init': (_i, [_vp, C.c_char_p, _vp]),
     'gpk_mg_set_option': (_i, [_vp, _i, _i]),
@@ -62,9 +63,12 @@ PROTOTYPES = {
     'gpk_prof_enable': (_i, [_vp, _i]),
     'gpk_prof_read': (_i, [_vp, _pd, _pi]),
     'gpk_prof_read_pipeline': (_i, [_vp, _pi, _pd, _pi]),
+    'gpk_prof_read_flops': (_i, [_vp, _pd, C.POINTER(C.c_long)]),
+    'gpk_prof_read_assembly': (_i, [_vp, _pd]),
     'gpk_assemble': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _d, _i, _vp, _i, _pd]),
     'gpk_assemble_test': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _i]),
     'gpk_extend': (_i, [_vp, _i, _i, _pd, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    'gpk_error_metrics': (_i, [_vp, _i, _vp, _vp, _vp, _pd, _pd]),
     'gpk_potrf': (_i, [_vp, _vp, _i, _i, _pi]),
     'gpk_tril': (_i, [_vp, _vp, _i, _i]),
     'gpk_symmetrize_lower': (_i, [_vp, _vp, _i, _i]),

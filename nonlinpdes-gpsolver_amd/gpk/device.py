@@ -278,6 +278,19 @@ class Context:
         self.synchronize()
         return out
 
+    def error_metrics(self, truth, approx):
+        """(|truth - approx| as a numpy array, its maximum, sqrt(sum of squares / n)) computed on the device (gpk_error_metrics);
+        truth / approx: host arrays or DeviceArrays of the same length"""
+        dt = truth if isinstance(truth, DeviceArray) else self.array(np.asarray(truth, dtype=np.float64).ravel())
+        da = approx if isinstance(approx, DeviceArray) else self.array(np.asarray(approx, dtype=np.float64).ravel())
+        n = dt.rows
+        if da.rows != n:
+            raise ValueError(f'error_metrics: {n} truth values against {da.rows} approximations')
+        err = DeviceArray(self, n)
+        mx, l2 = C.c_double(), C.c_double()
+        self._chk(self.lib.gpk_error_metrics(self.h, n, dt.ptr, da.ptr, err.ptr, C.byref(mx), C.byref(l2)))
+        return err.download(), mx.value, l2.value
+
     # ---- dense ----
     def potrf(self, A, n=None):
         n = A.rows if n is None else n
@@ -366,8 +379,19 @@ class Context:
         self._chk(self.lib.gpk_prof_read_pipeline(self.h, C.byref(pipelined), C.byref(syrk_launch), C.byref(cus)))
         # pipelined: syrk_ms is the wall time of the fused product + factorisation phase and potrf_ms is 0;
         # syrk_launch_ms = the SYRK launches themselves (events on the stream they ran on)
+        # flops the matrix-product launches of those steps executed, counted by the launch logic itself (gpk_prof_read_flops)
+        fl, nl = (C.c_double * 4)(), (C.c_long * 4)()
+        self._chk(self.lib.gpk_prof_read_flops(self.h, fl, nl))
         return dict(steps=n.value, trsm_ms=ms[0], syrk_ms=ms[1], potrf_ms=ms[2], trsv_update_ms=ms[3],
-                    pipelined=bool(pipelined.value), syrk_launch_ms=syrk_launch.value, chain_cus=cus.value)
+                    pipelined=bool(pipelined.value), syrk_launch_ms=syrk_launch.value, chain_cus=cus.value,
+                    solve_flops=fl[0], potrf_update_flops=fl[1], product_flops=fl[2],
+                    solve_launches=nl[0], potrf_update_launches=nl[1], product_launches=nl[2])
+
+    def prof_read_assembly(self):
+        """milliseconds of the evaluator launch of the last assemble call issued with prof_enable(True)"""
+        ms = C.c_double()
+        self._chk(self.lib.gpk_prof_read_assembly(self.h, C.byref(ms)))
+        return ms.value
 
     # ---- micro-benchmarks ----
     def ubench_mfma_f64(self, iters=20000):

@@ -97,18 +97,42 @@ class MultiGpu:
 
     # ---- communicators ------------------------------------------------------------------------------------------------
     def _init_rccl(self, group):
-        import torch
+        """Failure-symmetric over the ranks (advisor, round 3): every step that can fail on ONE rank before ncclCommInitRank -- loading
+        the library, finding its entry points, rank 0 obtaining the unique id -- is followed by an agreement over the caller's process
+        group, and only when every rank is ready does any of them enter ncclCommInitRank (which blocks until all have arrived).
+        On failure EVERY rank raises GpkError, so a caller's fallback takes the same branch everywhere."""
         import torch.distributed as dist
+        have_pg = dist.is_available() and dist.is_initialized()
+        if self.world > 1 and not have_pg:
+            raise GpkError("comm='rccl' with world > 1 needs an initialised torch.distributed process group to ship the unique id")
+
+        def agree(err):
+            """err: this rank's error text or ''.  Returns the first error over all ranks ('' if none); collective."""
+            if not have_pg:
+                return err
+            box = [None] * dist.get_world_size(group)
+            dist.all_gather_object(box, err, group=group)
+            return next((f'rank {r}: {e}' for r, e in enumerate(box) if e), '')
+
         path = torch_rccl_path()
         pb = path.encode() if path else None
+        ebuf = C.create_string_buffer(512)
+        rc = self.lib.gpk_mg_rccl_probe(pb, ebuf, 512)
+        err = agree('' if rc == 0 else f'cannot bind RCCL ({path}): {ebuf.value.decode(errors="replace")}')
+        if err:
+            raise GpkError('gpk_mg: ' + err)
         uid = (C.c_char * 128)()
+        uerr = ''
         if self.rank == 0:
             rc = self.lib.gpk_mg_rccl_unique_id(pb, uid)
             if rc != 0:
-                raise GpkError(f'gpk_mg_rccl_unique_id failed ({rc}); library {path}')
-        box = [bytes(uid.raw) if self.rank == 0 else None]
-        if self.world > 1 or (dist.is_available() and dist.is_initialized()):
-            dist.broadcast_object_list(box, src=0, group=group)  # 128 bytes through the process group's own transport
+                uerr = f'gpk_mg_rccl_unique_id failed ({rc}); library {path}'
+        # rank 0 ALWAYS takes part in the broadcast and ships either the id or an error marker
+        box = [(('ERR', uerr) if uerr else bytes(uid.raw)) if self.rank == 0 else None]
+        if have_pg:
+            dist.broadcast_object_list(box, src=0, group=group)   # 128 bytes through the process group's own transport
+        if isinstance(box[0], tuple):
+            raise GpkError('gpk_mg: rank 0: ' + box[0][1])
         uid2 = (C.c_char * 128).from_buffer_copy(box[0])
         self.ctx._chk(self.lib.gpk_mg_rccl_init(self.h, pb, uid2))
         self.comm_kind = f'rccl ({path})'
@@ -119,7 +143,7 @@ class MultiGpu:
         """ncclBroadcast / ncclAllGather stand-ins: wait for the stream, stage through host memory, torch.distributed (gloo)."""
         import torch
         import torch.distributed as dist
-        hip = C.CDLL('libamdhip64.so')
+        hip = C.CDLL(loaded_hip_runtime() or 'libamdhip64.so')   # the runtime this process has mapped, not whatever the search path yields
         hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         rank, world = self.rank, self.world

@@ -271,11 +271,13 @@ class ShardedFactorSolve:
         la = self.lookahead and nblk > 1
         plan = _mg.plan_potrf(n, nb, P, rank, la)
         have_streams = hasattr(ops, 'streams')
+        # the device-side pivot status is cleared on the main stream BEFORE the side streams are made to wait on it: FACTOR 0 runs on
+        # the panel stream with no WAIT in the plan, and must be ordered after the memset (the native executor does the same)
+        if hasattr(ops, 'info_reset'):
+            ops.info_reset()
         streams = ops.streams(la) if have_streams else (None, None, None)
         on = ops.on if have_streams else (lambda s: contextlib.nullcontext())
         events = {}
-        if hasattr(ops, 'info_reset'):
-            ops.info_reset()
         cap = n * min(nb, n)                                       # panel 0 is the largest
         for kind, a, b, s in plan:
             if self.trace is not None:

@@ -2,6 +2,7 @@
 -> errors, same bracket-tagged log lines.  Plot helpers use matplotlib when it is importable (no LaTeX requirement)."""
 import numpy as onp
 
+from ._runtime import get_context
 from .InverseProblems import Darcy_flow2d
 from .PDEs import Burgers, Eikonal, Nonlinear_elliptic2d
 
@@ -59,8 +60,10 @@ def _say(enabled, *keys, **fmt):
             print(_LOG[k].format(**fmt))
 
 
-def _rms_over(err, count):
-    return onp.sqrt(onp.sum(err ** 2) / count)
+def _as_vector(truth, n):
+    """the user's truth as n float64 values (a scalar truth -- e.g. 0 -- is broadcast like under jnp)"""
+    t = onp.asarray(truth, dtype=onp.float64)
+    return onp.full(n, float(t)) if t.ndim == 0 else t.ravel()
 
 
 class solver_GP(object):
@@ -122,12 +125,12 @@ class solver_GP(object):
             eqn.GN_relaxed_method(pen_lambda=pen_lambda, **gn)
         _say(print_option, 'gn_done')
 
-    # ---- errors (definitions of src/solver.py:175,191: root of the sum of squares over N_domain / N_test) ----------------
+    # ---- errors (definitions of src/solver.py:175,191: root of the sum of squares over N_domain / N_test), reduced on the device
+    # (gpk_error_metrics: |truth - value| per point, its maximum and sqrt(sum of squares / n) in one pass) ------------------------------
     def collocation_pts_err(self, truth, print_option=True):
         _say(print_option, 'pts_err')
-        self.pts_err_all = abs(onp.asarray(truth) - self.eqn.sol_sampled_pts)
-        self.pts_max_err = onp.max(self.pts_err_all)
-        self.pts_L2_err = _rms_over(self.pts_err_all, self.eqn.N_domain)
+        self.pts_err_all, self.pts_max_err, self.pts_L2_err = get_context().error_metrics(_as_vector(truth, self.eqn.N_domain),
+                                                                                             self.eqn.sol_sampled_pts)
         _say(print_option, 'pts_max', v=self.pts_max_err)
         _say(print_option, 'pts_l2', v=self.pts_L2_err)
 
@@ -137,9 +140,8 @@ class solver_GP(object):
 
     def get_test_error(self, truth, print_option=True):
         self.truth = truth
-        self.test_err_all = abs(onp.asarray(truth) - self.eqn.extended_sol)
-        self.test_max_err = onp.max(self.test_err_all)
-        self.test_L2_err = _rms_over(self.test_err_all, self.eqn.N_test)
+        self.test_err_all, self.test_max_err, self.test_L2_err = get_context().error_metrics(_as_vector(truth, self.eqn.N_test),
+                                                                                               self.eqn.extended_sol)
         _say(print_option, 'test_max', v=self.test_max_err)
         _say(print_option, 'test_l2', v=self.test_L2_err)
 

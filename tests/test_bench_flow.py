@@ -1,7 +1,8 @@
 """Control flow of bench.py with N > 1 ranks, on CPU: two gloo processes, the GPU-touching functions replaced by stubs.
 Checks what the driver relies on: every rank takes part in both phases (replicas of config 2, then the sharded config 5),
-exactly ONE JSON line comes out (rank 0), it carries n_gpus, the weak-scaling value of the replicas and the sharded run
-under sharded_config."""
+exactly ONE JSON line comes out (rank 0); since round 4 its `value` is the SHARDED config 5 (strong scaling) with the same
+configuration timed on rank 0 alone beside it (vs_1gpu) and the config-2 replicas as a secondary object -- and when the sharded
+run fails on one side, the replica line survives with the error attached."""
 import json
 import os
 import socket
@@ -28,14 +29,19 @@ def test_two_rank_flow_prints_one_line(tmp_path):
             t = comm.max_float(0.5 + comm.rank, 'cpu')           # slowest rank counts
             out = {{'metric': 'm', 'value': comm.world * args.steps / t, 'n_gpus': comm.world, 'scaling': 'weak', 'steps': args.steps}}
             return out if comm.rank == 0 else None
-        def fake_sharded(args, workload, steps=None, warmup=None):
-            assert workload == 'c5' and steps == min(args.steps, 3) and warmup == 1
+        def fake_sharded(args, workload, steps=None, warmup=None, solo=False):
+            assert workload == 'c5'
             import torch.distributed as dist
+            if solo:                                             # rank 0 alone: the 1-GPU point of the same job
+                assert dist.get_rank() == 0 and steps == min(args.steps, 3) and warmup == 1
+                return dict({{k: 1 for k in ('unit', 'steps', 'warmup', 'ms_per_step', 'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}},
+                            value=2.0, n_gpus=1, scaling='strong')
+            assert steps is None and warmup is None
             dist.barrier()
             if dist.get_rank() != 0:
                 return None
-            return {{k: 1 for k in ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'config', 'l2_error',
-                                   'f1_tflops', 'one_time_ms', 'roofline')}}
+            return dict({{k: 1 for k in ('unit', 'steps', 'warmup', 'ms_per_step', 'config', 'l2_error', 'f1_tflops', 'one_time_ms', 'roofline')}},
+                        metric='m', value=3.0, n_gpus=2, scaling='strong')
         bench.run_single, bench.run_sharded = fake_single, fake_sharded
         sys.argv = ['bench.py', '--gpus', '2', '--steps', '4', '--warmup', '1']
         bench.main()
@@ -51,9 +57,11 @@ def test_two_rank_flow_prints_one_line(tmp_path):
     lines = [l for o in outs for l in o[0].splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak'
-    assert abs(d['value'] - 2 * 4 / 1.5) < 1e-9                  # max over ranks of (0.5, 1.5)
-    assert d['sharded_config']['n_gpus'] == 1 and 'roofline' in d['sharded_config']
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['value'] == 3.0      # the sharded configuration IS the value
+    assert d['vs_1gpu'] == 1.5 and d['parallel_efficiency'] == 0.75 and d['one_gpu_same_job']['n_gpus'] == 1
+    assert d['replicas_c2']['scaling'] == 'weak'
+    assert abs(d['replicas_c2']['value'] - 2 * 4 / 1.5) < 1e-9   # max over ranks of (0.5, 1.5)
+    assert d['parity_failed'] is None
 
 
 def test_two_rank_flow_survives_a_one_sided_failure(tmp_path):
@@ -68,7 +76,7 @@ def test_two_rank_flow_survives_a_one_sided_failure(tmp_path):
             comm.barrier()
             out = {{'metric': 'm', 'value': 42.0, 'n_gpus': comm.world, 'scaling': 'weak', 'steps': args.steps}}
             return out if comm.rank == 0 else None
-        def fake_sharded(args, workload, steps=None, warmup=None):
+        def fake_sharded(args, workload, steps=None, warmup=None, solo=False):
             import torch.distributed as dist
             if dist.get_rank() == 1:
                 time.sleep(1.0)
@@ -90,7 +98,7 @@ def test_two_rank_flow_survives_a_one_sided_failure(tmp_path):
     lines = [l for o in outs for l in o[0].splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d['value'] == 42.0 and d['n_gpus'] == 2
+    assert d['value'] == 42.0 and d['n_gpus'] == 2 and 'NOT the strong-scaling figure' in d['fallback']
     assert 'out of memory (simulated)' in d['sharded_config']['error'] and 'rank 1' in d['sharded_config']['error']
 
 
@@ -121,11 +129,11 @@ def test_hanging_sharded_run_is_abandoned_at_the_deadline(tmp_path):
         import os, sys, time
         sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'nonlinpdes-gpsolver_amd'))
         import bench
-        bench.run_single = lambda args, workload, comm=None: {{'metric': 'm', 'value': 7.0, 'n_gpus': 1, 'steps': args.steps}}
-        def hang(args, workload, steps=None, warmup=None):
+        bench.run_single = lambda args, workload, comm=None, **kw: {{'metric': 'm', 'value': 7.0, 'n_gpus': 1, 'steps': args.steps}}
+        def hang(args, workload, steps=None, warmup=None, solo=False):
             time.sleep(3600)
         bench.run_sharded = hang
-        sys.argv = ['bench.py', '--steps', '4', '--warmup', '1']
+        sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--no-n10k', '--no-c3c4']
         bench.main()
     '''))
     env = dict(os.environ, GPK_SHARDED_TIMEOUT='2')

@@ -181,3 +181,21 @@ def test_other_drivers_run_small():
         r = subprocess.run([sys.executable] + args, cwd=pkg, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (args, r.stderr[-2000:])
         assert '[Gauss Newton] Gauss Newton iteration finished' in r.stdout and 'nan' not in r.stdout.lower(), r.stdout[-1500:]
+
+
+def test_error_metrics_on_device_match_the_reference_definitions():
+    """gpk_error_metrics against src/solver.py:175,191 of the reference: |truth - value|, its maximum, sqrt(sum of squares / n);
+    odd lengths, a NaN (propagates like jnp.max), and through solver_GP.get_test_error with a scalar truth"""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(11)
+    for n in (1, 63, 1024, 3601, 20001):
+        t, a = rng.normal(size=n), rng.normal(size=n)
+        err, mx, l2 = ctx.error_metrics(t, a)
+        np.testing.assert_array_equal(err, np.abs(t - a))
+        assert mx == np.max(np.abs(t - a))
+        assert l2 == pytest.approx(np.sqrt(np.sum((t - a) ** 2) / n), rel=1e-14)
+    t = rng.normal(size=100); a = t.copy(); a[37] = np.nan
+    _, mx, l2 = ctx.error_metrics(t, a)
+    assert np.isnan(mx) and np.isnan(l2)
+    ctx.close()
