@@ -15,6 +15,43 @@
 
 constexpr int GPK_MAX_TRSV_BLOCKS = 4096;
 
+// Piecewise-linear leading-zero profile ("staircase") of a block of right-hand sides: column c (storage order) is known to be zero
+// above row first_row(c).  Segment s covers the columns [c1[s-1], c1[s]) (c1[-1] = 0) with first_row(c) = a[s] + (b[s] - c) / sd[s]
+// (b[s] >= every c of the segment; sd huge = a flat step); columns from c1[nseg-1] on are dense.  The elliptic, Eikonal and Burgers
+// systems have ONE segment and keep the closed form (lead, lead_div) of gpk_i_gemm; the Darcy system's u-part has three (round 4):
+// slope 1 over the v1, v2 columns, flat over w1, w2, slope 1 over w0, v0 (gpk_gn.hip).  nseg = 0: no profile.
+struct GpkStair {
+    int nseg = 0;
+    int c1[4] = {0, 0, 0, 0};
+    int a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, sd[4] = {1, 1, 1, 1};
+};
+// smallest first_row over the columns [n0, n1) -- the row from which a tile with those columns has to start its K loop
+__host__ __device__ inline int gpk_stair_min(const GpkStair& st, int n0, int n1) {
+    int best = 0x7fffffff, lo = 0;
+    for (int s = 0; s < st.nseg; ++s) {
+        const int hi = st.c1[s];
+        const int x0 = n0 > lo ? n0 : lo, x1 = n1 < hi ? n1 : hi;    // overlap of the tile with the segment
+        if (x1 > x0) {                                               // non-increasing inside a segment: the right-most column decides
+            const int d = st.b[s] - (x1 - 1);
+            const int v = st.a[s] + (d > 0 ? d / st.sd[s] : 0);
+            best = v < best ? v : best;
+        }
+        lo = hi;
+    }
+    if (n1 > lo) best = 0;                                           // dense columns behind the last segment
+    return best == 0x7fffffff ? 0 : best;
+}
+// first column that can be non-zero in the rows [0, rows_end): the smallest c with first_row(c) < rows_end (profiles used by the
+// triangular solve are non-increasing in c); ncols if there is none
+inline int gpk_stair_first_col(const GpkStair& st, int rows_end, int ncols) {
+    int lo = 0, hi = ncols;                                          // invariant: first_row(c) >= rows_end for c < lo, < rows_end for c >= hi
+    while (lo < hi) {
+        const int mid = lo + (hi - lo) / 2;
+        if (gpk_stair_min(st, mid, mid + 1) < rows_end) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
 struct gpk_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -59,6 +96,10 @@ struct gpk_ctx {
     double* d_pts = nullptr;        // packed collocation points (SoA), grown on demand
     size_t pts_cap = 0;
     int num_cu = 256;
+    GpkStair stair;                 // piecewise staircase of the step being issued (nseg > 0: it replaces the closed form (lead, lead_div) in every
+                                    // launch that is given a non-zero `lead`); stair_col0 / stair_row0: global column of the launch's column 0 and
+                                    // global row of its k = 0, set by the caller around each gpk_i_gemm call
+    int stair_col0 = 0, stair_row0 = 0;
     int lead_div = 1;               // slope of the leading-zero staircase while a Gauss-Newton step is being issued: column c of the
                                     // right-hand side is zero above row (lead-1-c) / lead_div (1: elliptic, Eikonal; 3: Burgers)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // column-group streams of the multi-RHS triangular solve

@@ -1902,11 +1902,15 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
                          double* X, int ldx, int nrhs, int lead, int row0) {
     if (n <= 0 || nrhs <= 0) return 0;
     const int sd = h->lead_div > 0 ? h->lead_div : 1;                // staircase slope 1/sd: column c is zero above row (lead-1-c)/sd
-    int clo = lead - sd * (row0 + n);                                // (lead = 0: dense right-hand sides)
+    // piecewise profile (gpk_ctx::stair, Darcy): columns and rows are those of this call's top level (column 0 of B, row 0 of L); every
+    // product below is told where its column 0 / its k = 0 lie in that frame, and `lead` only says "there is a profile"
+    const bool pw = lead > 0 && h->stair.nseg > 0;
+    int clo = pw ? gpk_stair_first_col(h->stair, row0 + n, nrhs) : lead - sd * (row0 + n);   // (lead = 0: dense right-hand sides)
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
     if (n <= db) {
-        const int lz = lead - sd * row0 - clo;
+        const int lz = pw ? 1 : lead - sd * row0 - clo;
+        h->stair_col0 = clo; h->stair_row0 = row0;
         return gpk_i_gemm(h, false, false, n, nrhs - clo, n, 1.0, Dinv + (long)row0 * db, db, B + clo, ldb, 0.0, X + clo, ldx,
                           false, lz > 0 ? lz : 0, true);
     }
@@ -1915,10 +1919,11 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
     const int n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     GPK_TRY(gpk_i_trsm_left_dinv(h, L, Dinv, db, n1, ldl, B, ldb, X, ldx, nrhs, lead, row0));
-    int c1 = lead - sd * (row0 + n1);                                // X[rows of part 1] is zero left of this column
+    int c1 = pw ? gpk_stair_first_col(h->stair, row0 + n1, nrhs) : lead - sd * (row0 + n1);   // X[rows of part 1] is zero left of this column
     c1 = c1 > 0 ? (c1 / NB) * NB : 0;
     if (c1 < nrhs) {
-        const int lz = lead - sd * row0 - c1;
+        const int lz = pw ? 1 : lead - sd * row0 - c1;
+        h->stair_col0 = c1; h->stair_row0 = row0;
         if (g_solve_splitk && gpk_i_splitk_reserve(h) == 0) {
             // launches that fill the chip badly (a fraction of a wave, or 1.2 waves): more, shorter workgroups (split-K)
             const long t64 = (long)gpk_ceil_div(n2, 64) * gpk_ceil_div(nrhs - c1, 64);

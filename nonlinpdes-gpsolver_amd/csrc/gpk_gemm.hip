@@ -52,6 +52,8 @@ struct GemmArgs {
     int lead;          // operand B (stored [k][n]) has column n zero for k < lead-1-n: the tile with columns [n0, n0+BN)
                        // gets no contribution from k < lead - (n0 + BN), so its K loop starts there.  (SYRK S^T S,
                        // lower tiles: the A tile's columns are further right, i.e. non-zero even earlier.)
+    GpkStair stair;    // nseg > 0 (and lead > 0): the piecewise profile replaces the closed form -- the tile with columns [n0, n0+BN) starts at
+    int stair_col0, stair_row0;   // row gpk_stair_min(stair, stair_col0 + n0, stair_col0 + min(n0+BN, N)) - stair_row0 (Darcy system, gpk_gn.hip)
     int skip_upper;    // C is a block column whose top square is a diagonal block of a symmetric matrix: tiles entirely above
                        // that diagonal (m0 + BM <= n0) are not computed (their content is never read)
     int stagger;       // experiment, see the kernel
@@ -322,6 +324,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) 
         const int nlast = g.nsuper > 0 ? min((tn / SG_W) * SG_W + SG_W - 1, g.ntn - 1) * BN : n0;
         const int z = g.lead - (nlast + BN);
         kt0 = z > 0 ? (z / g.lead_div) / BK : 0;
+        if (g.stair.nseg > 0) {                                       // piecewise profile (wave-uniform: scalar ALU)
+            const int fr = gpk_stair_min(g.stair, g.stair_col0 + n0, g.stair_col0 + min(n0 + BN, g.N)) - g.stair_row0;
+            kt0 = fr > 0 ? fr / BK : 0;
+        }
         if (kt0 > nk) kt0 = nk;
     }
     int kbeg = kt0, kend = nk;                                       // this workgroup's slabs
@@ -628,6 +634,10 @@ void prof_count(gpk_handle h, const GemmArgs& g, int BM, int BN) {
         if (g.lead > 0) {
             const int z = g.lead - (n0 + BN);
             k0 = z > 0 ? ((z / g.lead_div) / BK) * BK : 0;
+            if (g.stair.nseg > 0) {
+                const int fr = gpk_stair_min(g.stair, g.stair_col0 + n0, g.stair_col0 + std::min(n0 + BN, g.N)) - g.stair_row0;
+                k0 = fr > 0 ? (fr / BK) * BK : 0;
+            }
         }
         if (g.tri_a) {
             for (int tm = 0; tm < ntm_full; ++tm) {
@@ -718,7 +728,7 @@ void sk_enumerate(const GemmArgs& g, std::vector<SkTile>& out) {
             const int z = g.lead - (n0 + BN);
             kt0 = z > 0 ? (z / g.lead_div) / BK : 0;
             if (kt0 > nk) kt0 = nk;
-        }
+        }                                                            // (launches with a piecewise profile never take tile lists: launch_cfg)
         out.push_back({tm, tn, kt0, nk});
     };
     if (g.lower_only) {
@@ -892,7 +902,7 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.nsuper = 0;
     prof_count(h, g, BM, BN);
     int nblocks = g.ntiles;
-    if (g.lower_only && g.lead > 0 && g_supertile && g.lead_div == 1) {
+    if (g.lower_only && g.lead > 0 && g_supertile && g.lead_div == 1 && g.stair.nseg == 0) {
         const int T = g.ntm, ncg = gpk_ceil_div(T, SG_W);
         for (int cg = 0; cg < ncg; ++cg) g.nsuper += gpk_ceil_div(T - cg * SG_W, SG_H);
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
@@ -931,7 +941,7 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     // Tile-list launch?  Resident workgroup slots of this configuration (waves per workgroup -> workgroups per CU: 4 waves 4 (5 for the
     // 32-row tile), 8 waves 2, 16 waves 1); worth it when the launch is only a few rounds of them -- then the last, partly filled
     // round and the spread of tile lengths (leading zeros, triangular operand) cost a large share of its time.
-    if (g_sk && g.splitk == 1 && g.nsuper == 0 && !h->no_sk && !g.rev_k && g.K >= 4 * BK && h->num_cu >= 8) {
+    if (g_sk && g.splitk == 1 && g.nsuper == 0 && !h->no_sk && !g.rev_k && g.K >= 4 * BK && h->num_cu >= 8 && g.stair.nseg == 0) {
         constexpr int WAVES = (BM / WM) * (BN / WN);
         const int per_cu = WAVES >= 16 ? 1 : WAVES >= 8 ? 2 : (BM == 32 ? 5 : 4);
         const int G = ((h->num_cu * per_cu) / 8) * 8;
@@ -1076,6 +1086,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     g.lower_only = lower_only ? 1 : 0;
     g.lead = (lead > 0 && !tb && (!lower_only || (ta && A == B))) ? lead : 0;
     g.lead_div = h->lead_div > 0 ? h->lead_div : 1;
+    g.stair = GpkStair(); g.stair_col0 = g.stair_row0 = 0;
+    if (g.lead > 0 && h->stair.nseg > 0) { g.stair = h->stair; g.stair_col0 = h->stair_col0; g.stair_row0 = h->stair_row0; }
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
     g.stagger = g_stagger;

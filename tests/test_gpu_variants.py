@@ -170,6 +170,49 @@ def test_burgers_leading_zero_layout_agrees_with_dense_schedule():
     ctx.close()
 
 
+@pytest.mark.parametrize('Nd,Nb,Ndata', [(333, 50, 20), (640, 128, 40), (1100, 150, 60)])
+def test_darcy_leading_zero_layout_agrees_with_dense_schedule(Nd, Nb, Ndata):
+    """Darcy system (round 4): gn_step orders the unknowns v1, v2, w1, w2, w0, v0; the u-part of A(z) then has a piecewise staircase
+    (slope 1, a flat step, slope 1 again -- GpkStair with three segments), the a-part a slope-1 staircase on a contiguous sub-range of
+    columns; the solve and the products skip the zeros above them.  gpk_debug_set(23, 0) runs the dense schedule.  Sizes that are not
+    multiples of anything (333: no column boundary of the profile is tile-aligned), exactly aligned (640) and several inverted blocks
+    (1100: factors of order 4550 / 3300).  Same operation -> same iterates; both against the oracle."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(Nd)
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = np.ones(Nd); g = np.zeros(Nb)
+    data = 0.05 * np.sin(np.pi * Xd[:Ndata, 0]) * np.sin(np.pi * Xd[:Ndata, 1]) + 1e-3 * rng.normal(size=Ndata)
+    Tu, _ = ctx.assemble('Darcy_u', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+    Ta, _ = ctx.assemble('Darcy_a', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+    assert ctx.potrf(Tu) == 0 and ctx.potrf(Ta) == 0
+    Lu, La = np.tril(Tu.download()), np.tril(Ta.download())
+    z0 = 0.3 * rng.normal(size=6 * Nd)
+    out = {}
+    try:
+        for mode in (1, 0):
+            ctx.lib.gpk_debug_set(23, mode)
+            prob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, f, g, Tu, p0=1e-3, data_u=data, L2=Ta)
+            z = ctx.array(z0)
+            hist = []
+            for _ in range(3):
+                loss, info = ctx.gn_step(prob, z)
+                assert info == 0
+                hist.append(loss)
+            hist.append(ctx.gn_loss(prob, z))
+            out[mode] = (z.download().copy(), np.array(hist))
+            prob.release_workspace()
+    finally:
+        ctx.lib.gpk_debug_set(23, 1)
+    assert np.linalg.norm(out[1][0] - out[0][0]) <= 1e-8 * np.linalg.norm(out[0][0])
+    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-7)
+    sysm = O.DarcySystem(f, g, data, 1e-3)
+    sol_ref, hist_ref = O.gn_method(sysm, [La, Lu], z0, 3, 1)
+    assert np.linalg.norm(out[1][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
+    np.testing.assert_allclose(out[1][1], hist_ref, rtol=1e-6)
+    ctx.close()
+
+
 @pytest.mark.parametrize('n', [64, 65, 130, 1000, 2049, 4001])
 def test_fused_panel_schedule_matches_separate_update_launches(n):
     """gpk_debug_set(48, .): the rank-64 work between two Cholesky panels rides inside the panel kernels (default: part B at the
