@@ -824,7 +824,9 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
     nugget = 1e-13
     mode_probe = {}
 
-    def set_mode(lookahead=None, shard_hb=None):
+    def set_mode(lookahead=None, shard_hb=None, overlap_s=None):
+        if overlap_s is not None and mgpu:
+            mgpu.set_option('overlap_s', int(overlap_s))
         if lookahead is not None:
             if mgpu:
                 mgpu.set_option('lookahead', int(lookahead))
@@ -915,6 +917,21 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
         mode_probe['step_ms_by_cholesky_of_Hb'] = times
         mode_probe['shard_hb_kept'] = bool(solver.shard_hb)
         warmup_run = 4
+        if mgpu:
+            # and for the exchange of the column shards of S: one all-gather, or one broadcast per shard on the communication stream with
+            # the block-row products of Hb issued behind the arrivals (native executor only; both once to warm up, then once timed)
+            xt = {}
+            for name, flag in (('all_gather', 0), ('broadcasts_chased_by_products', 1)) * 2:
+                set_mode(overlap_s=flag)
+                comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+                losses.append(step())
+                torch.cuda.synchronize()
+                xt[name] = comm.max_float(1e3 * (time.perf_counter() - t0), dev)
+            keep = int(xt['broadcasts_chased_by_products'] < xt['all_gather'])
+            set_mode(overlap_s=keep)
+            mode_probe['step_ms_by_exchange_of_S'] = xt
+            mode_probe['overlap_s_kept'] = bool(keep)
+            warmup_run += 4
     else:
         for _ in range(warmup):
             losses.append(step())

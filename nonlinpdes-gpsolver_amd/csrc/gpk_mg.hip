@@ -21,6 +21,8 @@ struct gpk_mg_ctx {
     gpk_handle h = nullptr;
     int rank = 0, world = 1, nb = 512;
     int lookahead = 0, shard_hb = 0, col_align = 128;
+    int overlap_s = 0;                     // step: 0 = one all-gather of the column shards of S, 1 = one broadcast per shard on the communication
+                                           // stream with the block-row products of Hb chasing the arrivals (gpk_mg_set_option key 3)
     void* comm = nullptr;
     gpk_mg_bcast_fn bcast = nullptr;
     gpk_mg_allgather_fn allgather = nullptr;
@@ -366,6 +368,7 @@ extern "C" int gpk_mg_set_option(gpk_mg_handle mg, int key, int value) {
     if (key == 0) { mg->lookahead = value != 0; return 0; }
     if (key == 1) { mg->shard_hb = value != 0; return 0; }
     if (key == 2 && value >= 1) { mg->col_align = value; return 0; }
+    if (key == 3) { mg->overlap_s = value != 0; return 0; }
     return gpk_bad_arg(mg->h, "gpk_mg_set_option: key / value");
 }
 
@@ -483,40 +486,84 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     for (int r = 0; r < P; ++r) per = std::max(per, b[r + 1] - b[r]);
     if (c1 > c0)
         GPK_TRY(gpk_i_trsm_left_dinv(h, p->L, p->Dinv, db, rows, p->ldl, S + c0, lds, S2 + c0, lds, c1 - c0, std::max(nz - c0, 0), 0));
-    // ---- all-gather of the column shards (padded to the widest; persistent staging buffers)
+    // ---- exchange of the column shards of S2, then my block rows (cyclic) of the lower triangle of Hb = S2^T S2 (structural zeros
+    //      skipped).  Two forms of the exchange (gpk_mg_set_option key 3; bench.py times both on the fabric and keeps the faster):
+    //      0: ONE all-gather (shards padded to the widest; persistent staging buffers), products afterwards;
+    //      1: one BROADCAST per shard, in rank order, on the communication stream (exact sizes, no padding); block row i only needs the
+    //         columns [0, i0 + ib), i.e. the shards up to the one that holds its last column -- its product is issued behind that
+    //         shard's event, so the early block rows are computed while the later shards are still travelling.
     const size_t shard = (size_t)rows * per;
     const int nblk = gpk_ceil_div(nc, nb), per_rank = gpk_ceil_div(nblk, P);
-    const size_t hrows = (size_t)per_rank * nb * ldh;
-    GPK_TRY(ensure_gather(mg, std::max(shard, hrows) * sizeof(double), std::max(shard, hrows) * P * sizeof(double)));
+    // the block rows travel as their LOWER parts only (round 4): block row i is ib x (i0 + ib); every rank's share padded to the largest
+    std::vector<size_t> share((size_t)P, 0);
+    for (int i = 0; i < nblk; ++i) { const int i0 = i * nb, ib = std::min(nb, nc - i0); share[i % P] += (size_t)ib * (size_t)(i0 + ib); }
+    const size_t hshare = *std::max_element(share.begin(), share.end());
+    (void)per_rank;
+    const size_t all_s = mg->overlap_s ? (size_t)rows * nc : shard * P;
+    GPK_TRY(ensure_gather(mg, std::max(shard, hshare) * sizeof(double), std::max(all_s, hshare * P) * sizeof(double)));
     if (c1 > c0)
-        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)per * 8, S2 + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)rows, hipMemcpyDeviceToDevice, s));
-    MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, shard, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of S");
-    for (int r = 0; r < P; ++r) {
-        const int a0 = b[r], a1 = b[r + 1];
-        if (r == rank || a1 <= a0) continue;
-        GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, mg->grecv + (size_t)r * shard, (size_t)per * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)(mg->overlap_s ? c1 - c0 : per) * 8, S2 + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)rows,
                                     hipMemcpyDeviceToDevice, s));
-    }
-    // ---- my block rows (cyclic) of the lower triangle of Hb = S2^T S2, structural zeros skipped
-    for (int i = rank; i < nblk; i += P) {
+    auto block_row = [&](int i) {
         const int i0 = i * nb, ib = std::min(nb, nc - i0);
-        GPK_TRY(gpk_i_gemm(h, true, false, ib, i0 + ib, rows, 1.0, S2 + i0, lds, S2, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, nz));
-    }
-    // ---- all-gather of the block rows (each is contiguous: ib x ldh)
-    {
-        int t = 0;
-        for (int i = rank; i < nblk; i += P, ++t) {
-            const int i0 = i * nb, ib = std::min(nb, nc - i0);
-            GPK_HIP(h, hipMemcpyAsync(mg->gsend + (size_t)t * nb * ldh, Hb + (long)i0 * ldh, (size_t)ib * ldh * 8, hipMemcpyDeviceToDevice, s));
+        return gpk_i_gemm(h, true, false, ib, i0 + ib, rows, 1.0, S2 + i0, lds, S2, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, nz);
+    };
+    if (!mg->overlap_s) {
+        MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, shard, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of S");
+        for (int r = 0; r < P; ++r) {
+            const int a0 = b[r], a1 = b[r + 1];
+            if (r == rank || a1 <= a0) continue;
+            GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, mg->grecv + (size_t)r * shard, (size_t)per * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+                                        hipMemcpyDeviceToDevice, s));
         }
-        MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, hrows, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of Hb");
+        for (int i = rank; i < nblk; i += P) GPK_TRY(block_row(i));
+    } else {
+        GPK_TRY(ensure_streams(mg, (size_t)P + 1));
+        const hipStream_t cs = mg->s_comm;
+        GPK_HIP(h, hipEventRecord(mg->ev_begin, s));                 // my shard is solved and packed
+        GPK_HIP(h, hipStreamWaitEvent(cs, mg->ev_begin, 0));
+        size_t off = 0;
+        for (int r = 0; r < P; ++r) {                                // every rank issues the same broadcasts in the same order
+            const int a0 = b[r], a1 = b[r + 1];
+            const size_t cnt = (size_t)rows * (size_t)(a1 - a0);
+            if (cnt > 0) {
+                double* dst = mg->grecv + off;
+                MG_NCCL(mg, mg->bcast(r == rank ? mg->gsend : dst, dst, cnt, NCCL_DOUBLE, r, mg->comm, (void*)cs), "broadcast of a shard of S");
+                if (r != rank)
+                    GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, dst, (size_t)(a1 - a0) * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+                                                hipMemcpyDeviceToDevice, cs));
+            }
+            GPK_HIP(h, hipEventRecord(mg->ev[r], cs));
+            off += cnt;
+        }
+        int waited = -1;                                             // shards 0 .. waited are known to the main stream
+        for (int i = rank; i < nblk; i += P) {
+            const int last_col = std::min(i * nb + nb, nc) - 1;
+            int need = 0;
+            while (need + 1 < P && b[need + 1] <= last_col) ++need;  // the shard that holds column last_col
+            if (need > waited) { GPK_HIP(h, hipStreamWaitEvent(s, mg->ev[need], 0)); waited = need; }
+            GPK_TRY(block_row(i));
+        }
+        if (waited < P - 1) GPK_HIP(h, hipStreamWaitEvent(s, mg->ev[P - 1], 0));   // join: the next collective of this communicator runs on s
+    }
+    // ---- all-gather of the block rows, lower parts only (block row i: ib rows of i0 + ib entries, packed)
+    {
+        size_t o = 0;
+        for (int i = rank; i < nblk; i += P) {
+            const int i0 = i * nb, ib = std::min(nb, nc - i0);
+            GPK_HIP(h, hipMemcpy2DAsync(mg->gsend + o, (size_t)(i0 + ib) * 8, Hb + (long)i0 * ldh, (size_t)ldh * 8, (size_t)(i0 + ib) * 8, (size_t)ib,
+                                        hipMemcpyDeviceToDevice, s));
+            o += (size_t)ib * (size_t)(i0 + ib);
+        }
+        MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, hshare, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of Hb");
         for (int r = 0; r < P; ++r) {
             if (r == rank) continue;
-            int tt = 0;
-            for (int i = r; i < nblk; i += P, ++tt) {
+            size_t oo = 0;
+            for (int i = r; i < nblk; i += P) {
                 const int i0 = i * nb, ib = std::min(nb, nc - i0);
-                GPK_HIP(h, hipMemcpyAsync(Hb + (long)i0 * ldh, mg->grecv + (size_t)r * hrows + (size_t)tt * nb * ldh, (size_t)ib * ldh * 8,
-                                          hipMemcpyDeviceToDevice, s));
+                GPK_HIP(h, hipMemcpy2DAsync(Hb + (long)i0 * ldh, (size_t)ldh * 8, mg->grecv + (size_t)r * hshare + oo, (size_t)(i0 + ib) * 8,
+                                            (size_t)(i0 + ib) * 8, (size_t)ib, hipMemcpyDeviceToDevice, s));
+                oo += (size_t)ib * (size_t)(i0 + ib);
             }
         }
     }

@@ -187,7 +187,7 @@ class MultiGpu:
 
     # ---- options / calls ----------------------------------------------------------------------------------------------
     def set_option(self, key, value):
-        keys = {'lookahead': 0, 'shard_hb': 1, 'col_align': 2}
+        keys = {'lookahead': 0, 'shard_hb': 1, 'col_align': 2, 'overlap_s': 3}
         self.ctx._chk(self.lib.gpk_mg_set_option(self.h, keys[key] if isinstance(key, str) else int(key), int(value)))
 
     def selftest(self):

@@ -370,22 +370,28 @@ class ShardedFactorSolve:
                 ops.gram_tn_lz(Hb, i0, 0, ib, i0 + ib, rows, S, i0, S, 0, nz)
             else:
                 ops.gram_tn(Hb, i0, 0, ib, i0 + ib, rows, S, i0, S, 0)
-        if P > 1:                                                  # all-gather the block rows (padded to equal counts)
-            per_rank = _ceil_div(nblk, P)
-            width = Hb.stride(0)
-            mine = self._staging('h_send', Hb, per_rank * nb * width).view(per_rank * nb, width)
-            for t, i in enumerate(range(rank, nblk, P)):
-                i0 = i * nb; ib = min(nb, nc - i0)
-                mine[t * nb:t * nb + ib, :nc].copy_(Hb[i0:i0 + ib, :nc])
-            allp = self._staging('h_recv', Hb, P * per_rank * nb * width)
+        if P > 1:
+            # all-gather of the block rows, LOWER parts only (round 4; whole rows until round 3: twice the bytes): block row i travels as
+            # ib x (i0 + ib) packed entries, every rank's share padded to the largest -- the layout of the native step (gpk_mg.hip)
+            blocks = [(i * nb, min(nb, nc - i * nb)) for i in range(nblk)]
+            share = [sum(ib * (i0 + ib) for i, (i0, ib) in enumerate(blocks) if i % P == r) for r in range(P)]
+            hshare = max(share)
+            mine = self._staging('h_send', Hb, hshare)
+            o = 0
+            for i in range(rank, nblk, P):
+                i0, ib = blocks[i]
+                mine[o:o + ib * (i0 + ib)].view(ib, i0 + ib).copy_(Hb[i0:i0 + ib, :i0 + ib])
+                o += ib * (i0 + ib)
+            allp = self._staging('h_recv', Hb, P * hshare)
             comm.all_gather_into(allp, mine)
             for r in range(P):
                 if r == rank:
                     continue
-                part = allp[r * per_rank * nb * width:(r + 1) * per_rank * nb * width].view(per_rank * nb, width)
-                for t, i in enumerate(range(r, nblk, P)):
-                    i0 = i * nb; ib = min(nb, nc - i0)
-                    Hb[i0:i0 + ib, :nc].copy_(part[t * nb:t * nb + ib, :nc])
+                o = r * hshare
+                for i in range(r, nblk, P):
+                    i0, ib = blocks[i]
+                    Hb[i0:i0 + ib, :i0 + ib].copy_(allp[o:o + ib * (i0 + ib)].view(ib, i0 + ib))
+                    o += ib * (i0 + ib)
         loss_dev = Hb[nz, nz].clone()                              # read on the host at the END of the step (one synchronisation)
         # Cholesky of the bordered matrix.  Replicated (every rank factors its own copy, no communication): at n_z = 16000 one GPU
         # needs ~37 ms, while the panel scheme pays per 512-wide panel an owner-only factorisation and a broadcast on top of
