@@ -1,7 +1,7 @@
 // gpk_bench.hip -- micro-benchmarks that fix the roofline denominators on the box the bench runs on.
 //   gpk_ubench_mfma_f64 : issue rate of v_mfma_f64_16x16x4_f64 (the local guides state no fp64 peak)
 //   gpk_ubench_hbm_write: streaming 8-byte-per-lane store bandwidth (the assembly kernel's access pattern)
-#include "gpk_common.h"
+#include "../gpk_common.h"
 
 namespace {
 typedef double d4 __attribute__((ext_vector_type(4)));

@@ -11,7 +11,7 @@
 //     ds_read_b64 of a fragment then touches 32 distinct bank pairs per half-wave.
 //   * THREE slab buffers (48 KB), two slabs in flight, ONE raw s_barrier per slab with a counted s_waitcnt vmcnt (the DMA writes
 //     are ordered for a reader only by the issuing wave's vmcnt followed by a barrier the reader has passed).
-#include "gpk_common.h"
+#include "../gpk_common.h"
 
 namespace {
 

@@ -273,7 +273,6 @@ template <int L> void diag_values(double p1, double p2, double (&c)[4]) {
 
 }  // namespace
 
-int g_asm_pairs = 1;                                                 // gpk_debug_set key 47: 0 = one column point per lane (8-byte stores) always
 
 extern "C" int gpk_assemble(gpk_handle h, int layout, int kernel, const double* kp, const double* Xd, int Nd,
                             const double* Xb, int Nb, double nugget, int nugget_type, double* Theta, int ld,
@@ -304,7 +303,7 @@ extern "C" int gpk_assemble(gpk_handle h, int layout, int kernel, const double* 
     }
     g.out = Theta; g.ld = ld;
     // two column points per lane (16-byte stores) when every pair (q, q + 1) stays inside one block and is 16-byte aligned
-    bool pairs = g_asm_pairs && (ld % 2 == 0) && (((uintptr_t)Theta & 15) == 0) && (g.M % 2 == 0);
+    bool pairs = h->tune.asm_pairs && (ld % 2 == 0) && (((uintptr_t)Theta & 15) == 0) && (g.M % 2 == 0);
     for (int b = 0; b < nb; ++b) pairs = pairs && (g.off[b] % 2 == 0) && (g.size[b] % 2 == 0);
     // (per-phase timing on: HIP events around the evaluator launch alone -- the point packing and the host work above stay outside)
     if (h->prof) {

@@ -8,6 +8,9 @@
 #include <vector>
 #include "../../include/gpk.h"
 #include "../../include/gpk_debug.h"
+#ifdef GPK_DEV
+#include "../../include/gpk_dev.h"
+#endif
 #include "../../include/gpk_mg.h"
 
 #define GPK_ERR_ARG (-9001)
@@ -52,7 +55,60 @@ inline int gpk_stair_first_col(const GpkStair& st, int rows_end, int ncols) {
     return lo;
 }
 
+// Development / tuning switches of ONE handle (round 4: they used to be process-wide globals).  Defaults are the measured choices;
+// gpk_tune(handle, key, value) (include/gpk_debug.h) changes one -- tests force every kernel variant through it, A/B measurements
+// flip one switch at a time.  The product path never calls gpk_tune.  "key N" = the key of gpk_tune.
+struct GpkTune {
+    int asm_pairs = 1;                  // key 47: 0 = one column point per lane (8-byte stores) always
+    int dbg = 0;                        // 
+    int mt_trsm = 0;                    // key 2: 
+    int persistent_ob = 0;              // key 7: 1 = persistent outer-block kernel (slower, see its header)
+    int left_looking_panels = 1;        // key 18: 0 = right-looking rank-64 updates also in the pipelined chain
+    int panel_mfma = 1;                 // key 21: 0 = first-design panel kernel (potf2_tile: two columns per barrier)
+    int panel_unrolled = 1;             // key 41: 0 = the rolled instantiation of the panel kernel
+    int fused_panel = 1;                // key 5: 0 = potf2 + trsm launches
+    int panel_fused = 1;                // key 48: 0 = rank-64 updates as launches of their own between the panel kernels (round 2)
+    int strip = 1;                      // key 3: 0 = 64-row base solves only
+    int solve_splitk = 0;               // key 30: largest split-K factor tried for the updates of the inverted-block solve (0 = off)
+    int potrf_pipeline_min_n = 2048;    // key 19: plain Cholesky pipelined for orders in [min, max] (max = 0: off, see gpk_i_potrf)
+    int potrf_pipeline_max_n = 0;       // key 20: plain Cholesky pipelined for orders in [min, max] (max = 0: off, see gpk_i_potrf)
+    int potrf_ob = 512;                 // key 51: outer block width of the right-looking factorisation (multiple of 64)
+    int pipeline = 1;                   // key 12: 0 = SYRK, then right-looking Cholesky, on one stream
+    int pipeline_chain_cus = 32;        // key 13: CUs of the chain partition (rounded to a multiple of 32)
+    int pipeline_pre = 1;               // key 17: blocks of the product computed before the fork
+    int pipeline_tile = 64;             // key 34: 64 / 128 = tile height of the pipeline's products (parallelism from split-K alone), 0 = automatic (32 rows below 512 tiles).  Phase time at config 2: automatic 3.18-3.23 ms, 64 rows 3.12-3.14, 128 rows 3.47
+    int pipeline_lookahead = 0;         // key 26: 0 = block j's update with block j-1 as ONE product after the chain of j-1
+    int pipeline_units = 1000;          // key 24: workgroups aimed at per product launch of the pipeline (split-K; 0 = no split).  Measured at config 2, phase time: 0 / 1000 / 1500 / 2000 / 3000 -> 3.85 / 3.57 / 3.58 / 3.60 / 3.62 ms
+    int pipeline_max_n = 7000;          // key 14: pipelined only up to this order (with the split-K products, product + factorisation per step: order 6001 7.18 -> 6.50 ms, 7001 13.7 -> 13.6, 8501 22.3 -> 23.3, 10001 35.8 -> 38.6)
+    int pipeline_w0 = 512;              // key 28: 
+    int pipeline_ob = 512;              // key 29: 
+    int probe_chain_cus = 0;            // key 11: overlap probe with a CU-mask partition
+    int fused_trsv = 1;                 // key 4: 0 = two launches per block, 1 = fused with data-tagged hand-offs (round 3), 2 = fused with flags (round 1)
+    int gemm_extra_lds = 0;             // key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
+    int k64_small = 1;                  // key 8: 0 = 64-row tiles only in the K <= 64 kernel
+    int band_mb = 192;                  // key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
+    int syrk_band = 256;                // key 36: MB of S per band of a large leading-zero SYRK launch (0 = column-major over all rows).  North-star size, the product S^T S: no bands 24.15 ms, 192 MB 23.4, 256 MB 22.9, 384 MB 23.55, 512 MB 24.3
+    int big_min = 6000;                 // key 38: launches with at least this many 64 x 64 tiles use the 128 x 128 tile with 16 waves, one workgroup per CU (0 = never).  tools/gemm_big_probe.py, 64 x 64 -> 128 x 64 -> this: NN 10500^3 60.0 / 58.6 / 65.2 TF/s, 8192^3 62.2 / 60.9 / 69.1 on a slow box; north-star solve phase 44.6 -> 43.7 ms with thresholds 3000 .. 6000; at config 2 (threshold 2000) the solve phase loses 5 %
+    int big_lower_min = 8000;           // key 50: lower-triangular leading-zero launches (S^T S) with at least this many lower 64 x 64 tiles use the 128 x 128 / 16-wave tile (0 = never)
+    int tall_min = 1500;                // key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
+    int force_splitk = 0;               // key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
+    int rev_k = 0;                      // key 16: 
+    int stagger = 0;                    // key 15: start-time stagger of co-resident GEMM workgroups (experiment)
+    int supertile = 0;                  // key 6: 1 = supertile schedule for the leading-zero SYRK (below)
+    int sk = 1;                         // key 42: 0 = never, 1 = automatic, 2 = every eligible launch
+    int sk_rounds = 6;                  // key 43: automatic mode uses tile lists for launches of fewer than this many rounds of resident workgroups
+    int sk_stagger = 2;                 // key 45: start stagger of the co-resident workgroups of a tile-list launch (slot x this x 512 cycles; every workgroup starts at once and has the same amount of work -- without it the four workgroups of a CU run in lock-step, see the kernel)
+    int sk_rowclass = 1;                // key 46: 0 = keep the launch's tile order when cutting shares (experiment)
+    int row_order = 0;                  // key 49: 1 = row-major, per-XCD-contiguous tile order for the narrow leading-zero products of the pipelined phase (experiment, round 3: fewer re-reads of S by construction, but slower -- sum of the product launches 2.14 -> 2.31 ms, phase 3.20 -> 3.39 ms at config 2, tools/row_order_ab.sh: longest-column-first matters more than the traffic)
+    int sk_snap = 4;                    // key 44: a share boundary closer than this many slabs to a tile boundary moves there
+    int force_cfg = 0;                  // key 0: development aid (): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
+    int use_dinv = 1;                   // key 10: 0 = substitution strips even when the inverses are supplied
+    int eikonal_lz = 1;                 // key 23: 0 = dense schedule for the Eikonal, Burgers and Darcy systems
+    int structured = 1;                 // key 40: 0 = ignore W1/W2/v0 (always the triangular solve); 1 = honour W1/W2/v0 only (never the Gram blocks); 2 would be redundant: the Gram level is used whenever G/pvec are set
+};
+
 struct gpk_ctx {
+    GpkTune tune;                   // development / tuning switches of this handle (gpk_tune)
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

@@ -183,6 +183,66 @@ extern "C" int gpk_timer_stop(gpk_handle h, double* ms) {
     return 0;
 }
 
+// Per-handle development / tuning switch (include/gpk_debug.h): one field of the handle's GpkTune (gpk_common.h, where every key is
+// documented next to its default).  No process-wide state: two handles of one process can run different variants side by side.
+extern "C" int gpk_tune(gpk_handle h, int key, int value) {
+    if (!h) return GPK_ERR_ARG;
+    GpkTune& t = h->tune;
+#ifndef GPK_DEV
+    // values that select a superseded design: those kernels are not in this library (csrc/dev/, libgpk_dev.so)
+    if ((key == 5 && value == 0) || (key == 7 && value != 0) || (key == 21 && value != 1) || (key == 4 && value == 2) || key == 11)
+        return gpk_bad_arg(h, "gpk_tune: this variant exists only in the development build (libgpk_dev.so)");
+#endif
+    switch (key) {
+        case 0: t.force_cfg = value; return 0;
+        case 2: t.mt_trsm = value; return 0;
+        case 3: t.strip = value; return 0;
+        case 4: t.fused_trsv = value; return 0;
+        case 5: t.fused_panel = value; return 0;
+        case 6: t.supertile = value; return 0;
+        case 7: t.persistent_ob = value; return 0;
+        case 8: t.k64_small = value; return 0;
+        case 9: t.gemm_extra_lds = value; return 0;
+        case 10: t.use_dinv = value; return 0;
+        case 11: t.probe_chain_cus = value; return 0;
+        case 12: t.pipeline = value; return 0;
+        case 13: t.pipeline_chain_cus = value; return 0;
+        case 14: t.pipeline_max_n = value; return 0;
+        case 15: t.stagger = value; return 0;
+        case 16: t.rev_k = value; return 0;
+        case 17: t.pipeline_pre = value; return 0;
+        case 18: t.left_looking_panels = value; return 0;
+        case 19: t.potrf_pipeline_min_n = value; return 0;
+        case 20: t.potrf_pipeline_max_n = value; return 0;
+        case 21: t.panel_mfma = value; return 0;
+        case 23: t.eikonal_lz = value; return 0;
+        case 24: t.pipeline_units = value; return 0;
+        case 25: t.force_splitk = value; return 0;
+        case 26: t.pipeline_lookahead = value; return 0;
+        case 28: t.pipeline_w0 = value; return 0;
+        case 29: t.pipeline_ob = value; return 0;
+        case 30: t.solve_splitk = value; return 0;
+        case 33: t.tall_min = value; return 0;
+        case 34: t.pipeline_tile = value; return 0;
+        case 35: t.band_mb = value; return 0;
+        case 36: t.syrk_band = value; return 0;
+        case 38: t.big_min = value; return 0;
+        case 40: t.structured = value; return 0;
+        case 41: t.panel_unrolled = value; return 0;
+        case 42: t.sk = value; return 0;
+        case 43: t.sk_rounds = value; return 0;
+        case 44: t.sk_snap = value; return 0;
+        case 45: t.sk_stagger = value; return 0;
+        case 46: t.sk_rowclass = value; return 0;
+        case 47: t.asm_pairs = value; return 0;
+        case 48: t.panel_fused = value; return 0;
+        case 49: t.row_order = value; return 0;
+        case 50: t.big_lower_min = value; return 0;
+        case 51: t.potrf_ob = value; return 0;
+        default: return gpk_bad_arg(h, "gpk_tune: unknown key");
+    }
+}
+
 extern "C" int gpk_prof_enable(gpk_handle h, int on) {
     if (!h) return GPK_ERR_ARG;
     if (on && !h->pev[0]) for (int i = 0; i < 5; ++i) GPK_HIP(h, hipEventCreate(&h->pev[i]));

@@ -7,14 +7,16 @@
 //
 // Structure: all O(n^3) work is delegated to gpk_i_gemm (MFMA); the diagonal blocks are handled by the kernels below.
 //   potrf(A)          = two-level right-looking (gpk_i_potrf): 512-column blocks, inside a block one fused panel kernel per 64
-//                       columns (potrf_panel_mfma_kernel, round 2; potrf_panel_kernel, round 1) + rank-64 updates
+//                       columns (potrf_panel_mfma_kernel) with the rank-64 updates riding inside (PanelFuse)
 //   syrk_potrf(W)     = chol(W^T W) of the Gauss-Newton step, product and factorisation pipelined by 512-column blocks on two
 //                       CU-mask partitions (gpk_i_syrk_potrf / potrf_pipelined)
 //   trsm_left(L)      = solve with L11; B2 -= L21 X1; solve with L22 (transposed: mirror image); leaves: 256-row strip kernel
 //   trsm_left_dinv(L) = the same recursion with leaves X_k = inv(L_kk) B_k: GEMMs only, for a factor that is used many times
 //                       (the inverses of its diagonal BLOCKS come from gpk_i_trtri_diag, by substitution; accuracy: see there)
 //   trsm_right_lt     = X1 <- X1 L11^{-T}; X2 -= X1 L21^T; X2 <- X2 L22^{-T}
-//   trsv              = single-vector solves in one launch, workgroups chained through flags (trsv_fused_kernel)
+//   trsv              = single-vector solves in one launch, workgroups chained through data-tagged granules (trsv_gran_kernel)
+// Superseded designs (first / third panel kernel, persistent outer-block kernel, flag-chained trsv, potf2 + row-solve launches) live
+// in dev/gpk_factor_retired.inc and are compiled into libgpk_dev.so only (-DGPK_DEV).
 // True substitution everywhere except trsm_left_dinv.  The recursions split at multiples of 64/128/256 so that sub-blocks stay
 // 16-byte aligned for the GEMM's vector loads.
 #include "gpk_common.h"
@@ -48,9 +50,14 @@ __device__ __forceinline__ void load_rows(const double* __restrict__ P, long ld,
 // v_readlane from the lane that owns them), then the trailing columns are updated from LDS in a loop whose body is
 // 16 FMAs fed by broadcast ds_read_b128.  Straight-line unrolling of the whole 64x64 factorisation (30+ KB of code
 // executed once by one wave) ran 4x slower than this: it is bound by instruction fetch, not by arithmetic.
-// development aid: phase time stamps (shader clock) of workgroup 0, enabled by gpk_debug_set(1, 1)
+// development aid: phase time stamps (shader clock) of workgroup 0 (gpk_debug_stamps) -- compiled into the development build only;
+// in the product library the `dbg` argument of the kernels is inert
+#ifdef GPK_DEV
 __device__ unsigned long long gpk_dbg_stamps[16];
 #define GPK_STAMP(i) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
+#else
+#define GPK_STAMP(i) do { } while (0)
+#endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -79,180 +86,6 @@ template <bool COH> __device__ __forceinline__ double ld_g(const double* p) {
 template <bool COH> __device__ __forceinline__ void st_g(double* p, double v) {
     if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
-}
-
-// stage a <=64 x <=64 diagonal block into LDS (identity-padded): one round trip, each wave fetches 16 rows
-__device__ __forceinline__ void potf2_stage(const double* __restrict__ A, long lda, int n, double* __restrict__ As) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cl = min(lane, n - 1);
-    double t[RB];
-#pragma unroll
-    for (int u = 0; u < RB; ++u) t[u] = A[(long)min(wave * RB + u, n - 1) * lda + cl];
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-        const int r = wave * RB + u;
-        As[r * XS + lane] = (r < n && lane < n) ? t[u] : ((r == lane) ? 1.0 : 0.0);   // identity padding
-    }
-}
-
-// in-place Cholesky of the staged block (As[r*XS + c], lower triangle valid on return); returns the 1-based index of the
-// first non-positive pivot (0 = none), wave-uniform.  Called by all 256 threads; ends with a barrier.
-// Unblocked right-looking, one barrier per column: thread = (row r, wave w) keeps 16 entries of row r in registers, the
-// columns {8i + 2w, 8i + 2w + 1}, i = 0..7 (cyclic in pairs, so all four waves stay busy to the last column and a pair is
-// one 16-byte broadcast read).  Column j: the wave that owns it takes the pivot from lane j, scales its column
-// (v_rsq_f64 + Newton, as LAPACK's dpotf2 scales by the reciprocal) and publishes it through a double-buffered LDS
-// vector; after the barrier every thread subtracts l[r] * l[c] from the columns c > j it owns.  The chain per column
-// is pivot broadcast -> rsqrt -> LDS round trip -> one FMA; the previous version (16-column panels factored redundantly
-// by every wave with 2 x (15 - j) lane broadcasts per column, then a blocked update) spent ~680 cycles per column.
-// TALL: the workgroup's own 64 rows BELOW the diagonal block ride along as extra rows of the right-looking loop (row r of
-// that block lives in xr[], same column ownership): scaling a column and subtracting the rank-2 terms is exactly the
-// column-oriented substitution X = B L^{-T}, so the row solve needs no pass of its own.  Finished columns of the extra
-// rows are written straight to memory (Xg: row block base, ldx, xrows valid rows).
-// the extra rows' entries this thread owns: columns {8i + 2w, 8i + 2w + 1}, i = 0..7, of row min(r, xrows-1)
-__device__ __forceinline__ void potf2_fetch_extra(const double* __restrict__ Xg, long ldx, int xrows, int n, double (&xr)[16]) {
-    const int r = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const double* __restrict__ xrow = Xg + (long)min(r, xrows - 1) * ldx;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        xr[2 * i] = xrow[min(8 * i + 2 * w, n - 1)];
-        xr[2 * i + 1] = xrow[min(8 * i + 2 * w + 1, n - 1)];
-    }
-}
-
-template <bool TALL>
-__device__ __forceinline__ int potf2_tile(double* __restrict__ As, double* __restrict__ Lc /* 8 x NB doubles, 16-byte aligned */, int n,
-                                          double* __restrict__ Xg = nullptr, long ldx = 0, int xrows = 0,
-                                          const double (*xpre)[16] = nullptr) {
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const int r = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // a[2k], a[2k+1]: columns 8 (o + k) + 2w, + 1 of row r, where o counts the finished groups of 8 columns -- the register
-    // file is ROTATED after every group so that the loop over groups can stay rolled with static register indices.
-    // (Fully unrolled, the 64 columns were 31 KB of straight-line code executed once per launch; rolled it is 8 KB.  The
-    // speed is the same, ~525 cycles per column = two rsqrt chains (~370 per pair) + LDS exchange and barrier (~250) +
-    // the rank-2 update of up to 16 register columns (~310): measured, tools/stamp_probe.py with GPK_DEBUG_SET=5=0.)
-    double a[16], xr[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        a[2 * i] = As[r * XS + 8 * i + 2 * w];
-        a[2 * i + 1] = As[r * XS + 8 * i + 2 * w + 1];
-    }
-    if (TALL) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) xr[i] = (*xpre)[i];             // fetched by the caller together with the diagonal block
-    }
-#pragma unroll 1
-    for (int o = 0; o < 8; ++o) {
-        const int jbase = 8 * o;
-        if (jbase >= n) break;
-        // Two columns per barrier: columns j, j+1 belong to the same wave (q), which finishes the first, applies it to the
-        // second in registers (one lane broadcast), finishes the second and publishes both; everybody then subtracts both
-        // rank-1 terms at once.  Lc holds 2 (parity of the pair) x 4 vectors of NB doubles (two columns of the diagonal
-        // block's rows, two of the extra rows).
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = jbase + 2 * q;
-            if (j < n) {
-                double* __restrict__ lc0 = Lc + (q & 1) * 4 * NB;
-                double* __restrict__ lc1 = lc0 + NB;
-                double* __restrict__ lx0 = lc0 + 2 * NB;
-                double* __restrict__ lx1 = lc0 + 3 * NB;
-                if (w == q) {
-                    double v[2] = {0.0, 0.0}, vx[2] = {0.0, 0.0};
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        if (t == 1) {
-                            if (j + 1 >= n) break;
-                            const double l10 = bcast_lane(v[0], j + 1);      // L[j+1][j]
-                            a[1] = fma(-v[0], l10, a[1]);
-                            if (TALL) xr[1] = fma(-vx[0], l10, xr[1]);
-                        }
-                        const double d = bcast_lane(a[t], j + t);        // pivot lives in lane j + t
-                        // 1/sqrt(d), sqrt(d) by coupled Newton iterations from v_rsq_f64: g -> sqrt(d), hh -> 1/(2 sqrt(d))
-                        const double y0 = __builtin_amdgcn_rsq(d);
-                        double g = d * y0, hh = 0.5 * y0;
-                        double e = fma(-g, hh, 0.5);
-                        g = fma(g, e, g); hh = fma(hh, e, hh);
-                        e = fma(-g, hh, 0.5);
-                        g = fma(g, e, g); hh = fma(hh, e, hh);
-                        const double sq = fma(fma(-g, g, d), hh, g);     // one more correction for the diagonal entry
-                        v[t] = (r == j + t) ? sq : a[t] * (hh + hh);     // LAPACK dpotf2 also scales by the reciprocal
-                        a[t] = v[t];
-                        if (TALL) { vx[t] = xr[t] * (hh + hh); xr[t] = vx[t]; }
-                    }
-                    lc0[r] = v[0];
-                    lc1[r] = v[1];
-                    if (TALL) { lx0[r] = vx[0]; lx1[r] = vx[1]; }
-                }
-                __syncthreads();
-                const double ml0 = lc0[r], ml1 = lc1[r];
-                const double mx0 = TALL ? lx0[r] : 0.0, mx1 = TALL ? lx1[r] : 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    if (k < 8 - o) {                                     // (uniform) groups that still exist
-                        const d2 m0 = *reinterpret_cast<const d2*>(lc0 + jbase + 8 * k + 2 * w);
-                        const d2 m1 = *reinterpret_cast<const d2*>(lc1 + jbase + 8 * k + 2 * w);
-                        const double u0 = fma(-ml1, m1.x, fma(-ml0, m0.x, a[2 * k]));
-                        const double u1 = fma(-ml1, m1.y, fma(-ml0, m0.y, a[2 * k + 1]));
-                        // in the group of the pair only the columns to the right of it (waves > q); the RESULT is selected,
-                        // so that a NaN column cannot reach finished columns (info)
-                        const bool take = (k > 0) || (w > q);
-                        a[2 * k] = take ? u0 : a[2 * k];
-                        a[2 * k + 1] = take ? u1 : a[2 * k + 1];
-                        if (TALL) {
-                            const double y0 = fma(-mx1, m1.x, fma(-mx0, m0.x, xr[2 * k]));
-                            const double y1 = fma(-mx1, m1.y, fma(-mx0, m0.y, xr[2 * k + 1]));
-                            xr[2 * k] = take ? y0 : xr[2 * k];
-                            xr[2 * k + 1] = take ? y1 : xr[2 * k + 1];
-                        }
-                    }
-                }
-            }
-        }
-        As[r * XS + jbase + 2 * w] = a[0];                               // this group is final
-        As[r * XS + jbase + 2 * w + 1] = a[1];
-#pragma unroll
-        for (int k = 0; k < 14; ++k) a[k] = a[k + 2];
-        if (TALL) {
-            if (r < xrows) {
-                double* __restrict__ xrow = Xg + (long)r * ldx;
-                if (jbase + 2 * w < n) xrow[jbase + 2 * w] = xr[0];
-                if (jbase + 2 * w + 1 < n) xrow[jbase + 2 * w + 1] = xr[1];
-            }
-#pragma unroll
-            for (int k = 0; k < 14; ++k) xr[k] = xr[k + 2];
-        }
-    }
-    __syncthreads();
-    // A non-positive (or NaN) pivot d gives rsqrt(d) = NaN or inf and a NaN on the diagonal, which then spreads: the
-    // first diagonal entry that is not > 0 marks the first bad pivot (LAPACK's info), every earlier one is finite.
-    const bool flag = (r < n) && !(As[r * XS + r] > 0.0);
-    const unsigned long long mask = __ballot(flag);
-    return mask ? (int)__builtin_ctzll(mask) + 1 : 0;
-}
-
-template <bool COH = false>
-__device__ __forceinline__ void potf2_store(double* __restrict__ A, long lda, int n, const double* __restrict__ As) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int u = 0; u < RB; ++u) {
-        const int r = wave * RB + u;
-        if (r < n && lane <= r) st_g<COH>(A + (long)r * lda + lane, As[r * XS + lane]);
-    }
-}
-
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, long lda, int n, int* info, int pivot_base, int dbg) {
-    GPK_STAMP(0);
-    __shared__ double As[NB * XS];                                  // As[r*XS + c]
-    __shared__ __attribute__((aligned(16))) double Ps[NB * RB];     // factored panel, Ps[r*16 + i] = L[r][r0+i]
-    potf2_stage(A, lda, n, As);
-    __syncthreads();
-    GPK_STAMP(1);
-    const int bad = potf2_tile<false>(As, Ps, n);
-    GPK_STAMP(2);
-    potf2_store(A, lda, n, As);
-    if (bad && bad <= n && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
-    GPK_STAMP(3);
 }
 
 // ---- substitution with a <=64-wide diagonal block: 4 cooperating waves per 64 right-hand sides ------------------------
@@ -388,56 +221,9 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
     trsm_base_body<TRANS, ROWVEC>(sh, L, ldl, nb, B, ldb, ncols, blockIdx.x, dbg);
 }
 
-// ---- Cholesky panel step, fused: factor the <=64-wide diagonal block AND solve the rows below against it ----------
-// ONE workgroup (the last) factors A_jj and writes it back; every other workgroup owns 64 rows below, factors its own copy of A_jj
-// in LDS (redundant, but off nobody's critical path: the alternative is a second launch that first waits for the
-// factor to travel through memory) with its 64 rows riding along as extra rows of the right-looking loop (potf2_tile<true>):
-// the scaled and updated extra rows ARE X = A_rj L_jj^{-T}.  One launch instead of two per panel, 41 KB of LDS.
-// A_jj is overwritten in place, so workgroup 0 may only store once every other workgroup has READ the unfactored block
-// -- including those the hardware dispatches late when the grid exceeds what is resident (n > ~16000).  Each workgroup
-// takes a ticket on a global counter after its loads have landed; the storing workgroup waits for the running total `target`
-// (the counter is never reset: the host passes the cumulative number of tickets).  Nobody ever waits for the storing workgroup,
-// and since round 2 that is the LAST workgroup of the grid: it waits only for workgroups that were dispatched before it.
-__global__ __launch_bounds__(256) void potrf_panel_kernel(double* __restrict__ A, long lda, int nb, int below,
-                                                          int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
-    // 37.4 KB of LDS in total: must stay below the 40 KB of a GEMM workgroup (four of those fill a CU's 160 KB), so that a
-    // panel workgroup fits into the slot a retiring GEMM workgroup frees when both run concurrently
-    __shared__ double As[NB * XS];
-    __shared__ __attribute__((aligned(16))) double Ps[8 * NB];       // potf2_tile's column exchange: 2 parities x 4 vectors
-    __builtin_amdgcn_s_setprio(3);                                   // latency chain: win issue arbitration against co-resident GEMM waves
-    const bool last = blockIdx.x + 1 == gridDim.x;                   // the LAST workgroup factors and stores A_jj (it only ever waits for workgroups dispatched before it)
-    const int c0 = (int)blockIdx.x * NB;                             // the others: my 64 rows below the diagonal block
-#define PANEL_STAMP(i) do { if (dbg && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
-    PANEL_STAMP(0);
-    double xr[16];
-    if (!last) potf2_fetch_extra(A + (long)(nb + c0) * lda, lda, min(NB, below - c0), nb, xr);   // same round trip as A_jj
-    potf2_stage(A, lda, nb, As);
-    __syncthreads();                                                 // every load of A_jj has landed (its value is in LDS)
-    PANEL_STAMP(1);
-    if (last) {
-        const int bad = potf2_tile<false>(As, Ps, nb);
-        __shared__ int expired;
-        if (threadIdx.x == 0) {
-            int it = 0, ex = 0;                                      // (int) difference: robust to wrap-around of the counter
-            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++it > (1 << 24)) { ex = 1; break; }             // the other workgroups never wait, so this means a lost
-            }                                                        // launch or a desynchronised counter: fail loudly
-            expired = ex;
-        }
-        __syncthreads();
-        if (expired) {                                               // do NOT overwrite a block somebody may still have to read
-            if (threadIdx.x == 0) atomicCAS(info, 0, -1);
-            return;
-        }
-        potf2_store(A, lda, nb, As);
-        if (bad && bad <= nb && threadIdx.x == 0) atomicCAS(info, 0, pivot_base + bad);
-    } else {
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        potf2_tile<true>(As, Ps, nb, A + (long)(nb + c0) * lda, lda, min(NB, below - c0), &xr);
-        PANEL_STAMP(2);
-    }
-}
+// (the first-design panel kernel, potrf_panel_kernel, and the contract it introduced -- the LAST workgroup factors A_jj in place, every
+// other workgroup factors its own copy with its 64 rows riding along, load tickets protect the in-place store -- live in
+// dev/gpk_factor_retired.inc; the contract is restated at the kernel below)
 
 // ---- Cholesky panel step, second design (round 2): narrow panels factored inside ONE wave, MFMA trailing updates ------------
 // Same contract as potrf_panel_kernel (workgroup 0 factors A_jj in place, workgroup b > 0 factors its own copy and its 64 rows
@@ -607,7 +393,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     double* __restrict__ Xg = A + (long)(nb + (tall ? c0 : 0)) * lda;   // my 64 rows below the diagonal block
     const bool rows_diag = (w < 2);                                  // waves 0, 1: rows of A_jj; waves 2, 3: extra rows
     const bool active = rows_diag || tall;
+#ifdef GPK_DEV
 #define PANEL_STAMP(i) do { if (dbg && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
+#else
+#define PANEL_STAMP(i) do { } while (0)
+#endif
     PANEL_STAMP(0);
     if (tid == 0) sh_bad = 0;
 
@@ -833,469 +623,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     if (xr < xrows && col < nb) Xg[(long)xr * lda + col] = acc[rt][ct][r];
                 }
     }
-}
-
-// ---- Cholesky panel step, third design (round 2): a dedicated factor wave that runs one panel ahead -----------------------
-// In potrf_panel_mfma_kernel the 8-column panels are handed back and forth: wave 0 factors panel p, every wave subtracts it from the
-// tile that holds panel p+1 on the matrix cores, stages that panel, and wave 0 picks it up -- of the ~4700 cycles per panel only
-// ~2050 are the factorisation, ~1950 are that hand-over (LDS reads -> MFMAs -> accumulator read-back -> staging -> barrier).
-// Here a FIFTH wave does nothing but factor, in "lane = row" form, and applies panel p to panel p+1 ITSELF (8 x 8 multipliers read
-// with v_readlane, 128 FMAs per lane for the two row sets); the four tile waves keep the working set in MFMA accumulators as before
-// but only have to deliver panel p+1 updated THROUGH p-1 -- which they do while the factor wave is busy with panel p.  Per panel,
-// one workgroup barrier:
-//     factor wave : factor p (registers) -> F[p&1]            | tile waves: tile(p+1) -= panel p-1 (from F[(p-1)&1]); stage panel p+1
-//                                                             |             into Q[(p+1)&1]; other tiles -= panel p-1; keep final p-1
-//     ------------------------------------------------ barrier ------------------------------------------------
-//     factor wave : (a, x) <- Q[(p+1)&1] - (panel p) * (multipliers of rows 8(p+1) .. 8(p+1)+7)
-// Same contract as the other two panel kernels (load tickets, in-place store by one workgroup, pivots -> info).
-// MEASURED (tools/panel_stamp_probe.py) and NOT the default (gpk_debug_set(21, 2) selects it): 39.1 k cycles per 64 columns against 42.8 k
-// for the second design -- the factor wave needs 3000 (factor + store) + 490 (apply; 2200 when the multipliers came through
-// v_readlane instead of LDS broadcasts) per panel, but the tile waves now need 4000 for their share (update, stage, deferred updates,
-// final values: the same LDS -> MFMA -> LDS latency chains, merely moved), so they set the pace.  And with 218 VGPRs only ONE such
-// workgroup fits a CU: on the 32-CU chain partition the 63 workgroups of a panel run in two rounds (pipelined phase 3.55 -> 4.2 ms),
-// on the whole chip the Cholesky of Theta does not gain either (9.1 -> 9.5 ms).  Kept as the scaffold for a version whose tile waves
-// are relieved (8 of them, or the deferred updates moved behind the barrier with a third F buffer).
-__device__ __forceinline__ int lane_rows_factor8(double (&a)[8], double (&x)[8], int p, int l) {
-    int bad = 0;
-    const int cb = __builtin_amdgcn_readfirstlane(8 * p);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int col = cb + j;
-        const double d = bcast_lane(a[j], col);                      // pivot (wave-uniform)
-        if (!(d > 0.0) && bad == 0) bad = col + 1;
-        const double y0 = __builtin_amdgcn_rsq(d);
-        double g = d * y0, hh = 0.5 * y0;
-        double e = fma(-g, hh, 0.5);
-        g = fma(g, e, g); hh = fma(hh, e, hh);
-        e = fma(-g, hh, 0.5);
-        g = fma(g, e, g); hh = fma(hh, e, hh);
-        const double sq = fma(fma(-g, g, d), hh, g);
-        const double rinv = hh + hh;
-        a[j] = (l == col) ? sq : a[j] * rinv;
-        x[j] = x[j] * rinv;
-#pragma unroll
-        for (int c = j + 1; c < 8; ++c) {
-            const double m = bcast_lane(a[j], cb + c);               // l[cb+c][col]
-            a[c] = fma(-a[j], m, a[c]);
-            x[c] = fma(-x[j], m, x[c]);
-        }
-    }
-    return bad;
-}
-
-__global__ __launch_bounds__(320) void potrf_panel_la_kernel(double* __restrict__ A, long lda, int nb, int below,
-                                                             int* info, int pivot_base, unsigned* loaded, unsigned target, int dbg) {
-    constexpr int PW = 8, PSW = PW + 2, KS = PW / 4, HPT = 16 / PW;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    __shared__ __attribute__((aligned(16))) double Fb[2][128 * PSW];   // factored panels (rows 0..63: L, 64..127: X)
-    __shared__ __attribute__((aligned(16))) double Qb[2][128 * PSW];   // panels staged for the factor wave
-    __shared__ int sh_bad, sh_expired;
-    const int tid = threadIdx.x, l = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool fw = (w == 4);                                        // the factor wave
-    const int li = l & 15, lk = l >> 4;
-    // The workgroup that stores A_jj in place is the LAST one: it waits for the tickets of workgroups with smaller indices only,
-    // which the hardware dispatches first.  (With workgroup 0 in that role -- the first two designs -- a grid that is not fully
-    // resident can starve: on a CU-masked partition with one CU per shader engine, workgroup 32 is bound to the CU on which
-    // workgroup 0 spins.  Those kernels stay below the limit, 3 workgroups per CU; this one holds one per CU.)
-    const bool tall = blockIdx.x + 1 < gridDim.x;
-    const int c0 = (int)blockIdx.x * NB;
-    const int xrows = tall ? min(NB, below - c0) : 0;
-    double* __restrict__ Xg = A + (long)(nb + (tall ? c0 : 0)) * lda;
-    const bool rows_diag = (w < 2);
-    const bool active = !fw && (rows_diag || tall);
-    __builtin_amdgcn_s_setprio(3);
-    PANEL_STAMP(0);
-    if (tid == 0) sh_bad = 0;
-
-    d4 acc[2][4];
-    if (!fw) {
-        const double* __restrict__ base = (rows_diag || !tall) ? A : Xg;
-        const int rmax = (rows_diag || !tall) ? nb - 1 : xrows - 1;
-        const int rlim = rows_diag ? nb : xrows;
-        const int rbase = 32 * (w & 1) + lk;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
-                    acc[rt][ct][r] = base[(long)min(row, rmax) * lda + min(col, nb - 1)];
-                }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rbase + 16 * rt + 4 * r, col = 16 * ct + li;
-                    const double pad = (rows_diag && row == col) ? 1.0 : 0.0;
-                    acc[rt][ct][r] = (row < rlim && col < nb) ? acc[rt][ct][r] : pad;
-                }
-    } else {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (d4){0.0, 0.0, 0.0, 0.0};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    auto stage = [&](double* __restrict__ P, int q, const d4 (&t0), const d4 (&t1)) {
-        if ((li / PW) == (q % HPT)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                P[(32 * w + lk + 4 * r) * PSW + (li % PW)] = t0[r];
-                P[(32 * w + 16 + lk + 4 * r) * PSW + (li % PW)] = t1[r];
-            }
-        }
-    };
-    auto update_static = [&](const double* __restrict__ P, auto lo_c, auto hi_c) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        double a0[KS], a1[KS], bf[4][KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            a0[ks] = -P[(32 * w + li) * PSW + 4 * ks + lk];
-            a1[ks] = -P[(32 * w + 16 + li) * PSW + 4 * ks + lk];
-        }
-#pragma unroll
-        for (int ct = LO; ct <= HI; ++ct)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) bf[ct][ks] = P[(16 * ct + li) * PSW + 4 * ks + lk];
-#pragma unroll
-        for (int ct = LO; ct <= HI; ++ct) {
-            if (16 * ct < nb) {
-                if (!rows_diag || 2 * w >= ct) {
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ks], bf[ct][ks], acc[0][ct], 0, 0, 0);
-                }
-                if (!rows_diag || 2 * w + 1 >= ct) {
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ks], bf[ct][ks], acc[1][ct], 0, 0, 0);
-                }
-            }
-        }
-    };
-    auto update_from = [&](const double* __restrict__ P, int lo, bool to_end) {
-        using std::integral_constant;
-        if (to_end) {
-            switch (lo) {
-                case 0: update_static(P, integral_constant<int, 0>{}, integral_constant<int, 3>{}); break;
-                case 1: update_static(P, integral_constant<int, 1>{}, integral_constant<int, 3>{}); break;
-                case 2: update_static(P, integral_constant<int, 2>{}, integral_constant<int, 3>{}); break;
-                case 3: update_static(P, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
-                default: break;
-            }
-        } else {
-            switch (lo) {
-                case 0: update_static(P, integral_constant<int, 0>{}, integral_constant<int, 0>{}); break;
-                case 1: update_static(P, integral_constant<int, 1>{}, integral_constant<int, 1>{}); break;
-                case 2: update_static(P, integral_constant<int, 2>{}, integral_constant<int, 2>{}); break;
-                case 3: update_static(P, integral_constant<int, 3>{}, integral_constant<int, 3>{}); break;
-                default: break;
-            }
-        }
-    };
-    // final values of panel q (factored, in P) into my tiles
-    auto keep_final = [&](const double* __restrict__ P, int q) {
-        const int tq = q / HPT;
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            if (ct == tq && (li / PW) == (q % HPT)) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[0][ct][r] = P[(32 * w + lk + 4 * r) * PSW + (li % PW)];
-                    acc[1][ct][r] = P[(32 * w + 16 + lk + 4 * r) * PSW + (li % PW)];
-                }
-            }
-        }
-    };
-    const int npan = (nb + PW - 1) / PW;
-    if (active) stage(Qb[0], 0, acc[0][0], acc[1][0]);               // panel 0, raw
-    if (!fw && !active) {                                            // workgroup 0, waves 2-3: the extra rows are zero padding
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (li < PW) { Qb[0][(32 * w + lk + 4 * r) * PSW + li] = 0.0; Qb[0][(32 * w + 16 + lk + 4 * r) * PSW + li] = 0.0;
-                           Qb[1][(32 * w + lk + 4 * r) * PSW + li] = 0.0; Qb[1][(32 * w + 16 + lk + 4 * r) * PSW + li] = 0.0; }
-        }
-    }
-    __syncthreads();
-    if (tall && tid == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket: A_jj has been read
-    PANEL_STAMP(1);
-
-    double a[8], x[8];
-    if (fw) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const d2 t = *reinterpret_cast<const d2*>(Qb[0] + l * PSW + 2 * i);
-            a[2 * i] = t.x; a[2 * i + 1] = t.y;
-            const d2 u = *reinterpret_cast<const d2*>(Qb[0] + (64 + l) * PSW + 2 * i);
-            x[2 * i] = u.x; x[2 * i + 1] = u.y;
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        if (p >= npan) break;                                        // (unrolled: every tile index a constant, see potrf_panel_mfma_kernel)
-        double* __restrict__ Fc = Fb[p & 1];
-        const double* __restrict__ Fp = Fb[(p + 1) & 1];             // factored panel p-1
-        double* __restrict__ Qn = Qb[(p + 1) & 1];                   // panel p+1 for the factor wave
-        if (p == 2) PANEL_STAMP(3);
-        if (fw) {
-            if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[8] = clock64();
-            const int bad = lane_rows_factor8(a, x, p, l);
-            if (bad && l == 0 && sh_bad == 0) sh_bad = bad;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<d2*>(Fc + l * PSW + 2 * i) = (d2){a[2 * i], a[2 * i + 1]};
-                *reinterpret_cast<d2*>(Fc + (64 + l) * PSW + 2 * i) = (d2){x[2 * i], x[2 * i + 1]};
-            }
-            if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[9] = clock64();
-        } else if (active) {
-            const int tn = (p + 1) / HPT;
-            if (p > 0) {
-                if (p + 1 < npan) update_from(Fp, tn, false);        // the tile with panel p+1 first
-            }
-            if (p + 1 < npan) {
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    if (ct == tn) stage(Qn, p + 1, acc[0][ct], acc[1][ct]);
-            }
-            if (p > 0) {
-                if (p + 1 < npan) update_from(Fp, tn + 1, true);     // the tiles further right
-                keep_final(Fp, p - 1);
-            }
-        }
-        if (p == 2) PANEL_STAMP(4);
-        __syncthreads();
-        if (p == 2) PANEL_STAMP(5);
-        if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[10] = clock64();
-        if (fw && p + 1 < npan) {
-            double an[8], xn[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const d2 t = *reinterpret_cast<const d2*>(Qn + l * PSW + 2 * i);
-                an[2 * i] = t.x; an[2 * i + 1] = t.y;
-                const d2 u = *reinterpret_cast<const d2*>(Qn + (64 + l) * PSW + 2 * i);
-                xn[2 * i] = u.x; xn[2 * i + 1] = u.y;
-            }
-            // the 8 x 8 multipliers L[8(p+1)+c][8p+j] come back from F as LDS broadcast reads (every lane the same address): as
-            // 128 v_readlane the step took 2200 cycles, more than the factorisation
-            const int cn = __builtin_amdgcn_readfirstlane(8 * (p + 1));
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                double m[8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const d2 t = *reinterpret_cast<const d2*>(Fc + (cn + c) * PSW + 2 * i);
-                    m[2 * i] = t.x; m[2 * i + 1] = t.y;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    an[c] = fma(-a[j], m[j], an[c]);
-                    xn[c] = fma(-x[j], m[j], xn[c]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { a[c] = an[c]; x[c] = xn[c]; }
-            if (p == 2 && dbg && blockIdx.x == 1 && tid == 256) gpk_dbg_stamps[11] = clock64();
-        }
-        if (p == 2) PANEL_STAMP(6);
-    }
-    if (active) keep_final(Fb[(npan - 1) & 1], npan - 1);            // (written before the loop's last barrier)
-    PANEL_STAMP(2);
-
-    if (!tall) {
-        __syncthreads();
-        if (tid == 0) {
-            int it = 0, ex = 0;
-            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++it > (1 << 24)) { ex = 1; break; }
-            }
-            sh_expired = ex;
-        }
-        __syncthreads();
-        if (sh_expired) {
-            if (tid == 0) atomicCAS(info, 0, -1);
-            return;
-        }
-        if (rows_diag) {
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 32 * w + 16 * rt + lk + 4 * r, col = 16 * ct + li;
-                        if (row < nb && col <= row) A[(long)row * lda + col] = acc[rt][ct][r];
-                    }
-        }
-        const int bad = sh_bad;
-        if (bad && bad <= nb && tid == 0) atomicCAS(info, 0, pivot_base + bad);
-    } else if (!rows_diag && !fw) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int xr = 32 * (w - 2) + 16 * rt + lk + 4 * r, col = 16 * ct + li;
-                    if (xr < xrows && col < nb) Xg[(long)xr * lda + col] = acc[rt][ct][r];
-                }
-    }
-}
-
-// ---- Cholesky of one outer block column (<= 512 columns, all rows below) in ONE persistent launch -----------------------
-// Workgroup r owns the 64-row block r of the block column.  For panel j = 0 .. J-1 (64 columns each):
-//   r == j : factor the diagonal tile (potf2_tile), write it back, raise flag D[j]; done.
-//   r >  j : wait for D[j]; X_r = A_rj L_jj^{-T} by substitution (trsm_base_body, the tile was fetched before the wait);
-//            raise X[r][j] if r < J (other row blocks need X_r as the column operand); then apply the rank-64 update of
-//            panel j to the tiles this workgroup still has to the right: A_rc -= X_r X_c^T, c = j+1 .. min(r, J-1), with
-//            X_c read from memory once flag X[c][j] is up (c == r: its own X, still in LDS).  MFMA, 32 x 32 per wave.
-// So the only thing between two diagonal factorisations is: flag hand-off, one 64 x 64 substitution and one tile
-// update in workgroup j+1 -- the rank-64 update launch (12.6 us) and the row solves of everybody else are off the chain.
-// A workgroup waits only for workgroups with a smaller blockIdx (dispatched earlier): no deadlock even when the grid
-// exceeds what is resident.  Flags carry the launch epoch (never cleared).  Tiles that cross workgroups (L_jj, X_c) are
-// stored write-through and loaded cache-bypassing (ld_g / st_g), so a hand-off costs a s_waitcnt, not an L2 write-back +
-// invalidate; a workgroup's own tiles stay in its XCD's L2, and the diagonal tile goes from the last update straight into
-// LDS for the factorisation.
-// MEASURED (round 1, tools/potrf_probe.py) and therefore OFF by default: 50-59 us per panel against 40-46 us for the
-// launch-per-panel path.  The chain workgroup runs wait (the owner's potf2, 17 us) -> substitution (13 us) -> tile
-// update (7.6 us) -> its own potf2 (17 us): the same latency-bound pieces, now strictly serial in one workgroup, whereas
-// the launch-per-panel path lets every workgroup start its copy of the factorisation at launch.  Kept (and covered by
-// tests/test_gpu_variants.py) as the scaffold for a version with a faster substitution.
-struct ObShared {
-    union {
-        struct { double As[NB * XS]; __attribute__((aligned(16))) double Ps[NB * RB]; } f;   // diagonal factorisation
-        TrsmShared t;                                                                       // substitution + own X (t.Ys)
-    } u;
-    __attribute__((aligned(16))) double Xc[NB * WS];                 // partner tile X_c, [n][k]
-};
-
-__device__ __forceinline__ bool ob_wait(const int* flag, int epoch) {
-    int it = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++it > (1 << 22)) return false;
-    }
-    return true;
-}
-
-// C (global, mr x nc valid) -= X_r X_c^T over kpad (multiple of 4) columns; X_r from t.Ys ([k][m], stride XS); X_c either
-// from Ys as well (OWN: the diagonal tile of this row block) or from Xc ([n][k], stride WS).
-// OUT = 0: store to memory; OUT = 1: keep the result in LDS (As, identity-padded) for the factorisation that follows.
-template <bool OWN, int OUT>
-__device__ __forceinline__ void ob_tile_update(double* __restrict__ Cg, long ldc, int mr, int nc, const double* __restrict__ Ys,
-                                               const double* __restrict__ Xc, int kpad, double* __restrict__ As) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int wm = (w >> 1) * 32, wn = (w & 1) * 32;
-    d4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm + 16 * i + lk + 4 * r, col = wn + 16 * j + li;
-                acc[i][j][r] = Cg[(long)min(row, mr - 1) * ldc + min(col, nc - 1)];
-            }
-    for (int ks = 0; ks < kpad; ks += 4) {
-        double a[2], b[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = -Ys[(ks + lk) * XS + wm + 16 * i + li];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = OWN ? Ys[(ks + lk) * XS + wn + 16 * j + li] : Xc[(wn + 16 * j + li) * WS + ks + lk];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm + 16 * i + lk + 4 * r, col = wn + 16 * j + li;
-                if (OUT == 1) As[row * XS + col] = (row < mr && col < nc) ? acc[i][j][r] : ((row == col) ? 1.0 : 0.0);
-                else if (row < mr && col < nc) Cg[(long)row * ldc + col] = acc[i][j][r];
-            }
-}
-
-__global__ __launch_bounds__(256) void potrf_ob_kernel(double* __restrict__ A, long lda, int nrows, int ob, int* flags, int epoch,
-                                                       int* info, int pivot_base, int dbgs) {
-    __shared__ ObShared sh;
-    const int r = blockIdx.x, tid = threadIdx.x;
-    const int J = (ob + NB - 1) / NB;
-    const int mr = min(NB, nrows - NB * r);                          // rows of this block
-    const int dbg = 0;
-#define OB_STAMP(i) do { if (dbgs && blockIdx.x == 1 && threadIdx.x == 0) gpk_dbg_stamps[i] = clock64(); } while (0)
-    OB_STAMP(0);
-    bool ok = true;
-    bool staged = false;                                             // the (updated) diagonal tile already sits in LDS
-    for (int j = 0; j <= min(r, J - 1); ++j) {
-        const int nbj = min(NB, ob - NB * j);                        // width of panel j
-        double* const Tjj = A + (long)(NB * j) * lda + NB * j;
-        if (r == j) {
-            if (!staged) potf2_stage(Tjj, lda, nbj, sh.u.f.As);      // (only workgroup 0: nobody touched its tile)
-            __syncthreads();
-            OB_STAMP(5);
-            const int bad = potf2_tile<false>(sh.u.f.As, sh.u.f.Ps, nbj);
-            OB_STAMP(6);
-            potf2_store<true>(Tjj, lda, nbj, sh.u.f.As);
-            if (bad && bad <= nbj && tid == 0) atomicCAS(info, 0, pivot_base + NB * j + bad);
-            gpk_drain_stores();                                      // every storing wave waits for its own write-through stores
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(&flags[8 * j + j], ok ? epoch : -epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            OB_STAMP(7);
-            break;
-        }
-        // ---- r > j: my tile of panel j, fetched before the wait
-        const int below = nrows - NB * (j + 1);
-        double* const Bj = Tjj + (long)nbj * lda;                    // first row below the diagonal tile (nbj = 64 whenever r > j exists)
-        double tx[RB];
-        trsm_base_fetch<true>(Bj, lda, nbj, below, r - j - 1, tx);
-        OB_STAMP(1);
-        if (tid == 0) ok = ob_wait(&flags[8 * j + j], epoch) && ok;
-        __syncthreads();
-        OB_STAMP(2);
-        trsm_base_body<false, true, true>(sh.u.t, Tjj, lda, nbj, Bj, lda, below, r - j - 1, dbg, &tx);   // X_r -> memory and t.Ys
-        if (r < J) {
-            gpk_drain_stores();
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(&flags[8 * j + r], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        OB_STAMP(3);
-        const int kpad = ((nbj + 3) / 4) * 4;
-        for (int c = j + 1; c <= min(r, J - 1); ++c) {
-            const int ncc = min(NB, ob - NB * c);                    // width of column block c
-            double* const Trc = A + (long)(NB * r) * lda + NB * c;
-            if (c == r) {
-                __syncthreads();
-                if (j + 1 == r) {                                    // next: this workgroup factors the tile -- keep it in LDS
-                    ob_tile_update<true, 1>(Trc, lda, mr, ncc, sh.u.t.Ys, nullptr, kpad, sh.u.f.As);
-                    staged = true;
-                } else {
-                    ob_tile_update<true, 0>(Trc, lda, mr, ncc, sh.u.t.Ys, nullptr, kpad, nullptr);
-                }
-            } else {
-                if (tid == 0) ok = ob_wait(&flags[8 * j + c], epoch) && ok;
-                __syncthreads();                                     // (also: the previous update has finished with Xc)
-                const double* Tcj = A + (long)(NB * c) * lda + NB * j;
-#pragma unroll
-                for (int u = 0; u < RB; ++u) {                       // X_c: 64 rows x nbj columns, zero-padded in k
-                    const int n = (tid >> 6) * RB + u, k = tid & 63;
-                    const double v = ld_g<true>(Tcj + (long)n * lda + min(k, nbj - 1));
-                    sh.Xc[n * WS + k] = (k < nbj) ? v : 0.0;
-                }
-                __syncthreads();
-                ob_tile_update<false, 0>(Trc, lda, mr, ncc, sh.u.t.Ys, sh.Xc, kpad, nullptr);
-            }
-        }
-        __syncthreads();                                             // t.Ys / Xc are free again
-        OB_STAMP(4);
-    }
-    if (!ok && tid == 0) atomicCAS(info, 0, -1);                     // a bounded wait expired: cannot happen (see above)
 }
 
 // ---- forward substitution with a <=256-wide diagonal block, fused: one launch per 256-row strip ------------------------
@@ -1528,105 +855,10 @@ __global__ __launch_bounds__(64) void trsv_diag_kernel(const double* __restrict_
     if (lane < nb) x[lane] = res;
 }
 
-// ---- single-vector triangular solve, fused: ONE launch, workgroup w owns the w-th 64-equation block in solve order -----
-// T x = b with T = L (forward) or L^T (backward).  Workgroup w accumulates  sum_d T[w][d] x_d  over the blocks d solved
-// before it, in solve order, waiting for each x_d on a per-block flag in global memory (value = launch epoch, so the
-// flags never need clearing), then solves its diagonal block by substitution (one wave, lane = equation) and publishes
-// x_w.  A workgroup only ever waits for workgroups with a smaller blockIdx, which the hardware dispatches first, so the
-// wait chain cannot deadlock; the spin is bounded anyway and poisons the result with NaN if it ever expires.
-// Visibility across the eight XCD-private L2s: x_w is stored with agent-scope atomic stores (write-through) and the
-// flag store follows once they have been acknowledged (explicit s_waitcnt vmcnt(0), gpk_drain_stores); readers poll the flag and read x_d with agent-scope atomic loads
-// (cache-bypassing) -- no L2 write-back / invalidate fence on the chain.  The 64 x 64 coefficient tiles are single-use and prefetched one dependency ahead, independent of the flags.
-// Measured: 329 us for n = 4000 backward (5.2 us per link of the chain: release, flag visibility, poll, acquire, the
-// x_d loads, 64 substitution steps).  Tried and slower: the chain on a single XCD (tile stream on 32 CUs only, 698 us);
-// four dependencies per round trip (serial flag polls, 449 us).
-// Replaces 2 launches per block (diagonal solve 7 us + GEMV 7 us, 63 blocks = 0.83 ms per Gauss-Newton step at n_z = 4000).
-template <bool TRANS>
-__global__ __launch_bounds__(256) void trsv_fused_kernel(const double* __restrict__ L, long ldl, int n, double* x,
-                                                         int* flags, int epoch) {
-    __shared__ double T[NB * (NB + 1)];
-    __shared__ double part[4][NB];
-    const int nblk = (n + NB - 1) / NB;
-    const int w = blockIdx.x;
-    const int bid = TRANS ? nblk - 1 - w : w;
-    const int r0 = bid * NB, nb = min(NB, n - r0);
-    const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;         // thread = equation r, columns 16q .. 16q+15 of a tile
-    const int rc = min(r, nb - 1);
-
-    // tile (w, d), element (r, c): forward L[r0 + r][c0 + c] (thread = row r, 16 consecutive columns: one 128-byte line);
-    // backward L[c0 + c][r0 + r] (lanes = consecutive addresses).  Indices are clamped (branch-free loads); what lies
-    // out of range is multiplied by x = 0 or never stored.
-    auto load_tile = [&](int d, double (&t)[16]) {
-        const int dbid = TRANS ? nblk - 1 - d : d;
-        const int c0 = dbid * NB, cnb = min(NB, n - c0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = min(q * 16 + i, cnb - 1);
-            t[i] = TRANS ? L[(long)(c0 + c) * ldl + r0 + rc] : L[(long)(r0 + rc) * ldl + c0 + c];
-        }
-    };
-    double tcur[16], tnext[16];
-    if (w > 0) load_tile(0, tcur);
-    {   // diagonal block -> LDS, identity-padded
-        double dv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) dv[u] = L[(long)(r0 + min(q * 16 + u, nb - 1)) * ldl + r0 + rc];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int row = q * 16 + u;
-            T[row * (NB + 1) + r] = (row < nb && r < nb) ? dv[u] : ((row == r) ? 1.0 : 0.0);
-        }
-    }
-    double acc = 0.0;
-    bool dead = false;
-    for (int d = 0; d < w; ++d) {
-        if (d + 1 < w) load_tile(d + 1, tnext);
-        const int dbid = TRANS ? nblk - 1 - d : d;
-        if (tid == 0) {
-            int it = 0;
-            while (__hip_atomic_load(&flags[dbid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++it > (1 << 22)) { dead = true; break; }
-            }
-        }
-        __syncthreads();                                             // (x_d is read with cache-bypassing loads: no acquire fence)
-        const int c0 = dbid * NB, cnb = min(NB, n - c0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = q * 16 + i;
-            const double v = __hip_atomic_load(&x[c0 + min(c, cnb - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc = fma(tcur[i], (c < cnb) ? v : 0.0, acc);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) tcur[i] = tnext[i];
-    }
-    part[q][r] = acc;
-    __syncthreads();
-    if (q == 0) {                                                    // wave 0: substitution on the diagonal block
-        double b = (r < nb) ? x[r0 + r] - ((part[0][r] + part[1][r]) + (part[2][r] + part[3][r])) : 0.0;
-        const double rd = 1.0 / T[r * (NB + 1) + r];
-        double res = 0.0;
-        if (!TRANS) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const double xj = bcast_lane(b * rd, j);
-                if (r == j) res = xj;
-                b = fma(-T[r * (NB + 1) + j], xj, b);                // L[r][j]; only lanes > j matter
-            }
-        } else {
-#pragma unroll
-            for (int j = NB - 1; j >= 0; --j) {
-                const double xj = bcast_lane(b * rd, j);
-                if (r == j) res = xj;
-                b = fma(-T[j * (NB + 1) + r], xj, b);                // L[j][r]; only lanes < j matter
-            }
-        }
-        if (__builtin_amdgcn_readfirstlane((int)dead)) res = __builtin_nan("");
-        if (r < nb) __hip_atomic_store(&x[r0 + r], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gpk_drain_stores();                                          // this wave's write-through stores have been acknowledged
-        if (r == 0) __hip_atomic_store(&flags[bid], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
+#ifdef GPK_DEV
+#include "dev/gpk_factor_retired.inc"   // retired designs (round 1 / 2): potf2 + row-solve launches, first and third panel kernels,
+                                         // persistent outer-block kernel, flag-chained single-vector solve -- development build only
+#endif
 
 // ---- the same solve with DATA-TAGGED hand-offs (round 3) -------------------------------------------------------------------
 // In trsv_fused_kernel a link of the chain costs 4.1 us: x_w goes out as 64 write-through stores, the wave waits for their
@@ -1770,15 +1002,6 @@ __global__ __launch_bounds__(1024) void dot_kernel(const double* __restrict__ x,
     }
 }
 
-int g_dbg = 0;
-int g_mt_trsm = 0;
-int g_persistent_ob = 0;                                             // gpk_debug_set key 7: 1 = persistent outer-block kernel (slower, see its header)
-int g_left_looking_panels = 1;                                       // gpk_debug_set key 18: 0 = right-looking rank-64 updates also in the pipelined chain
-int g_panel_mfma = 1;                                                // gpk_debug_set key 21: 0 = first-design panel kernel (potf2_tile: two columns per barrier)
-int g_panel_unrolled = 1;                                            // gpk_debug_set key 41: 0 = the rolled instantiation of the panel kernel
-int g_fused_panel = 1;                                               // gpk_debug_set key 5: 0 = potf2 + trsm launches
-int g_panel_fused = 1;                                               // gpk_debug_set key 48: 0 = rank-64 updates as launches of their own between the panel kernels (round 2)
-int g_strip = 1;                                                      // gpk_debug_set key 3: 0 = 64-row base solves only
 
 inline int split(int n, int base = NB) {
     // first part: about half, a multiple of 128 when there is room (keeps GEMM operands aligned and tiles full);
@@ -1798,19 +1021,19 @@ inline int split(int n, int base = NB) {
 
 int gpk_i_trsm_left(gpk_handle h, bool trans, const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
     if (n <= 0 || nrhs <= 0) return 0;
-    if (!trans && g_strip && n <= SB && (n & 15) == 0) {
-        trsm_strip_kernel<<<gpk_ceil_div(nrhs, SNC), SNT, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
+    if (!trans && h->tune.strip && n <= SB && (n & 15) == 0) {
+        trsm_strip_kernel<<<gpk_ceil_div(nrhs, SNC), SNT, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, h->tune.dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
     if (n <= NB) {
         dim3 grid(gpk_ceil_div(nrhs, NB));
-        if (trans) trsm_base_kernel<true, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
-        else       trsm_base_kernel<false, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, g_dbg);
+        if (trans) trsm_base_kernel<true, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, h->tune.dbg);
+        else       trsm_base_kernel<false, false><<<grid, 256, 0, h->stream>>>(L, ldl, n, B, ldb, nrhs, h->tune.dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    const int n1 = split(n, (!trans && g_strip && n > SB) ? SB : NB), n2 = n - n1;
+    const int n1 = split(n, (!trans && h->tune.strip && n > SB) ? SB : NB), n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     const double* L22 = L21 + n1;
     double* B2 = B + (long)n1 * ldb;
@@ -1837,17 +1060,17 @@ int gpk_i_trsm_left_lz(gpk_handle h, const double* L, int n, int ldl, double* B,
     int clo = lead - sd * (row0 + n);
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
-    if (g_strip && n <= SB && (n & 15) == 0) {
-        trsm_strip_kernel<<<gpk_ceil_div(nrhs - clo, SNC), SNT, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, g_dbg);
+    if (h->tune.strip && n <= SB && (n & 15) == 0) {
+        trsm_strip_kernel<<<gpk_ceil_div(nrhs - clo, SNC), SNT, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, h->tune.dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
     if (n <= NB) {
-        trsm_base_kernel<false, false><<<gpk_ceil_div(nrhs - clo, NB), 256, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, g_dbg);
+        trsm_base_kernel<false, false><<<gpk_ceil_div(nrhs - clo, NB), 256, 0, h->stream>>>(L, ldl, n, B + clo, ldb, nrhs - clo, h->tune.dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    const int n1 = split(n, (g_strip && n > SB) ? SB : NB), n2 = n - n1;
+    const int n1 = split(n, (h->tune.strip && n > SB) ? SB : NB), n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     double* B2 = B + (long)n1 * ldb;
     GPK_TRY(gpk_i_trsm_left_lz(h, L, n1, ldl, B, nrhs, ldb, lead, row0));
@@ -1882,7 +1105,6 @@ __global__ void dinv_identity_kernel(double* __restrict__ D, int n, int db) {
     if (i < (long)n * db) D[i] = ((i / db) % db == i % db) ? 1.0 : 0.0;
 }
 
-int g_solve_splitk = 0;                                              // gpk_debug_set key 30: largest split-K factor tried for the updates of the inverted-block solve (0 = off)
 inline bool dinv_block_ok(int db) { return db == 256 || db == 512 || db == 1024 || db == 2048; }
 
 int gpk_i_trtri_diag(gpk_handle h, const double* L, int n, int ldl, double* Dinv, int db) {
@@ -1924,14 +1146,14 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
     if (c1 < nrhs) {
         const int lz = pw ? 1 : lead - sd * row0 - c1;
         h->stair_col0 = c1; h->stair_row0 = row0;
-        if (g_solve_splitk && gpk_i_splitk_reserve(h) == 0) {
+        if (h->tune.solve_splitk && gpk_i_splitk_reserve(h) == 0) {
             // launches that fill the chip badly (a fraction of a wave, or 1.2 waves): more, shorter workgroups (split-K)
             const long t64 = (long)gpk_ceil_div(n2, 64) * gpk_ceil_div(nrhs - c1, 64);
             const bool small = t64 < 2 * h->num_cu;                  // (gpk_i_gemm then uses 32-row tiles, 5 per CU)
             const long tiles = small ? (long)gpk_ceil_div(n2, 32) * gpk_ceil_div(nrhs - c1, 64) : t64;
             const long slots = (long)h->num_cu * (small ? 5 : 4);
             int best = 1; double bc = 1e30;
-            for (int s2 = 1; s2 <= g_solve_splitk; ++s2) {
+            for (int s2 = 1; s2 <= h->tune.solve_splitk; ++s2) {
                 const double c = (double)((tiles * s2 + slots - 1) / slots) / s2 + 0.04 * (s2 - 1);
                 if (c < bc - 1e-9) { bc = c; best = s2; }
             }
@@ -1953,7 +1175,7 @@ int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl
     // Measured at N=8400, nrhs=4001 (round 1): 17.9 ms with 4 groups vs 11.0 ms single-stream -- four times as many
     // launches of smaller GEMMs cost more than the overlap buys.  Kept behind gpk_debug_set(2, 1) for re-evaluation
     // once the diagonal solves are fused into fewer launches.
-    if (!g_mt_trsm || nrhs < 1024 || n <= 2 * NB) return gpk_i_trsm_left(h, trans, L, n, ldl, B, nrhs, ldb);
+    if (!h->tune.mt_trsm || nrhs < 1024 || n <= 2 * NB) return gpk_i_trsm_left(h, trans, L, n, ldl, B, nrhs, ldb);
     if (!h->ev_fork) {
         GPK_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < G - 1; ++i) {
@@ -1989,7 +1211,7 @@ int gpk_i_trsm_left_mt(gpk_handle h, bool trans, const double* L, int n, int ldl
 int gpk_i_trsm_right_lt(gpk_handle h, const double* L, int n, int ldl, double* X, int m, int ldx) {
     if (n <= 0 || m <= 0) return 0;
     if (n <= NB) {
-        trsm_base_kernel<false, true><<<gpk_ceil_div(m, NB), 256, 0, h->stream>>>(L, ldl, n, X, ldx, m, g_dbg);
+        trsm_base_kernel<false, true><<<gpk_ceil_div(m, NB), 256, 0, h->stream>>>(L, ldl, n, X, ldx, m, h->tune.dbg);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
@@ -2017,22 +1239,24 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
     // ev_rec_pre: recorded once every panel but the last has been factored (the pipeline starts the next block's update with those)
     if (ob <= 0 || nrows < ob) return 0;
     const int npan = gpk_ceil_div(ob, NB);
-    if (g_persistent_ob) {
+#ifdef GPK_DEV                                                       // retired variant (dev/gpk_factor_retired.inc): development build only
+    if (h->tune.persistent_ob) {
         if (ev_wait_p1) GPK_HIP(h, hipStreamWaitEvent(h->stream, (hipEvent_t)ev_wait_p1, 0));
         if (++h->ob_epoch == 0x7fffffff) {
             GPK_HIP(h, hipMemsetAsync(h->d_obflags, 0, 64 * sizeof(int), h->stream));
             h->ob_epoch = 1;
         }
-        potrf_ob_kernel<<<gpk_ceil_div(nrows, NB), 256, 0, h->stream>>>(A, lda, nrows, ob, h->d_obflags, h->ob_epoch, h->d_info, pivot_base, g_dbg);
+        potrf_ob_kernel<<<gpk_ceil_div(nrows, NB), 256, 0, h->stream>>>(A, lda, nrows, ob, h->d_obflags, h->ob_epoch, h->d_info, pivot_base, h->tune.dbg);
         GPK_LAUNCH_CHECK(h);
         if (ev_rec_pre) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));
         return 0;
     }
-    // FUSED schedule (g_panel_fused, default): the rank-64 work between two panels rides inside the panel kernels (PanelFuse above)
+#endif
+    // FUSED schedule (h->tune.panel_fused, default): the rank-64 work between two panels rides inside the panel kernels (PanelFuse above)
     // Right-looking schedule (whole chip) only: on the 32-CU chain partition of the pipelined phase the product workgroups sit on the
     // same CUs as the panel workgroups and slow them down (co-residence, the very reason for the CU partition): measured 3.13 -> 3.26 ms
-    // for the phase at config 2 with the left-looking chain fused, so that chain keeps its separate launches (g_panel_fused = 2 forces it).
-    const bool fused = g_panel_fused && (g_panel_fused == 2 || !left_looking) && g_fused_panel && g_panel_mfma == 1 && g_panel_unrolled && !ev_wait_p1 && !ev_rec_pre;
+    // for the phase at config 2 with the left-looking chain fused, so that chain keeps its separate launches (h->tune.panel_fused = 2 forces it).
+    const bool fused = h->tune.panel_fused && (h->tune.panel_fused == 2 || !left_looking) && h->tune.fused_panel && h->tune.panel_mfma == 1 && h->tune.panel_unrolled && !ev_wait_p1 && !ev_rec_pre;
     for (int j0 = 0; j0 < ob; j0 += NB) {
         const int nb = (ob - j0 < NB) ? ob - j0 : NB;
         double* Ajj = A + (long)j0 * lda + j0;
@@ -2060,7 +1284,7 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             }
             const int extra = f.gK > 0 ? gpk_ceil_div(f.gm, PFM) * f.gtn : 0;
             potrf_panel_mfma_kernel<8, true, true><<<1 + nrb + extra, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                            (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg, f);
+                                                                                            (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, f);
             GPK_LAUNCH_CHECK(h);
             h->panel_loaded = target;
             continue;
@@ -2080,31 +1304,41 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             // idea INSIDE the panel kernel, see PanelFuse.)
             GPK_TRY(gpk_i_gemm(h, false, true, nrows - j0, nb, j0, -1.0, A + (long)j0 * lda, lda, A + (long)j0 * lda, lda, 1.0, Ajj, lda, false));
         }
-        if (g_fused_panel) {
+        {
             const int nrb = below > 0 ? gpk_ceil_div(below, NB) : 0;
             const unsigned target = h->panel_loaded + (unsigned)nrb;
             PanelFuse nofuse;
             memset(&nofuse, 0, sizeof nofuse);
-            if (g_panel_mfma == 2)
+            bool launched = false;
+#ifdef GPK_DEV                                                       // retired variants (dev/gpk_factor_retired.inc): development build only
+            if (!h->tune.fused_panel) {                              // round 1, before the fused panel step: potf2 + row solve as two launches
+                potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, h->tune.dbg);
+                if (below > 0)
+                    trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, h->tune.dbg);
+                GPK_LAUNCH_CHECK(h);
+                launched = true;
+            } else if (h->tune.panel_mfma == 2) {                    // third design (factor wave one panel ahead)
                 potrf_panel_la_kernel<<<1 + nrb, 320, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
-            else if (g_panel_mfma) {
-                if (g_panel_unrolled)
+                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg);
+                GPK_LAUNCH_CHECK(h);
+                h->panel_loaded = target; launched = true;
+            } else if (h->tune.panel_mfma == 0) {                    // first design (two columns per barrier)
+                potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                    (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg);
+                GPK_LAUNCH_CHECK(h);
+                h->panel_loaded = target; launched = true;
+            }
+#endif
+            if (!launched) {
+                if (h->tune.panel_unrolled)
                     potrf_panel_mfma_kernel<8, true><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                      (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg, nofuse);
+                                                                                      (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, nofuse);
                 else
                     potrf_panel_mfma_kernel<8, false><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg, nofuse);
+                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, nofuse);
+                GPK_LAUNCH_CHECK(h);                                 // a failed launch issues no tickets: count them only now
+                h->panel_loaded = target;
             }
-            else
-            potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, g_dbg);
-            GPK_LAUNCH_CHECK(h);                                     // a failed launch issues no tickets: count them only now
-            h->panel_loaded = target;
-        } else {
-            potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, g_dbg);
-            if (below > 0)
-                trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, g_dbg);
         }
         if (ev_rec_pre && j0 / NB == npan - 2) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));   // (this panel's columns are final)
         if (below > 0 && !left_looking) {
@@ -2124,14 +1358,10 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
 
 static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss,
                            int pivot_base);
-extern int g_pipeline;
-int g_potrf_pipeline_min_n = 2048, g_potrf_pipeline_max_n = 0;      // gpk_debug_set keys 19 / 20: plain Cholesky pipelined for orders in
-                                                                     // [min, max] (max = 0: off, see gpk_i_potrf)
 
-int g_potrf_ob = 512;                                                // gpk_debug_set key 51: outer block width of the right-looking factorisation (multiple of 64)
 static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     if (n <= 0) return 0;
-    const int OB = (g_potrf_ob >= 64 && g_potrf_ob % 64 == 0) ? g_potrf_ob : 512;
+    const int OB = (h->tune.potrf_ob >= 64 && h->tune.potrf_ob % 64 == 0) ? h->tune.potrf_ob : 512;
     for (int k0 = 0; k0 < n; k0 += OB) {
         const int ob = (n - k0 < OB) ? n - k0 : OB;
         GPK_TRY(gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, ob, lda, pivot_base + k0));
@@ -2146,7 +1376,7 @@ static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 }
 
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
-    if (g_pipeline && !h->pipe_unavailable && n >= g_potrf_pipeline_min_n && n <= g_potrf_pipeline_max_n && h->num_cu >= 64)
+    if (h->tune.pipeline && !h->pipe_unavailable && n >= h->tune.potrf_pipeline_min_n && n <= h->tune.potrf_pipeline_max_n && h->num_cu >= 64)
         return potrf_pipelined(h, nullptr, 0, 0, n, 0, A, lda, nullptr, pivot_base);
     return potrf_seq(h, A, n, lda, pivot_base);
 }
@@ -2166,26 +1396,18 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 //     chain stream, block j: wait for U_j; gpk_i_potrf_panel (64-column panel kernels + rank-64 updates inside the block)
 // The chain of block j runs next to S_{j+1} and the early part of U_{j+1}.  Same flops as the right-looking order (plus the
 // upper triangles of the 512 x 512 diagonal blocks, which are computed and never read).
-int g_pipeline = 1;                                                  // gpk_debug_set key 12: 0 = SYRK, then right-looking Cholesky, on one stream
-int g_pipeline_chain_cus = 32;                                       // gpk_debug_set key 13: CUs of the chain partition (rounded to a multiple of 32)
 // The partition costs the GEMM side a quarter of the chip, the chain side roughly doubles the time of its rank-64 updates;
 // the overlap pays while the panel chain (~34 us per 64 columns) is comparable to the GEMM work (~n^3): measured 4.24 -> 3.96 ms
 // at n = 4001 (BASELINE config 2) but 35.9 -> 43.8 ms at n = 10001, break-even near n = 5500.
-int g_pipeline_pre = 1;                                              // gpk_debug_set key 17: blocks of the product computed before the fork
-int g_pipeline_tile = 64;                                           // gpk_debug_set key 34: 64 / 128 = tile height of the pipeline's products (parallelism from split-K alone), 0 = automatic (32 rows below 512 tiles).  Phase time at config 2: automatic 3.18-3.23 ms, 64 rows 3.12-3.14, 128 rows 3.47
-int g_pipeline_lookahead = 0;                                        // gpk_debug_set key 26: 0 = block j's update with block j-1 as ONE product after the chain of j-1
-int g_pipeline_units = 1000;                                          // gpk_debug_set key 24: workgroups aimed at per product launch of the pipeline (split-K; 0 = no split).  Measured at config 2, phase time: 0 / 1000 / 1500 / 2000 / 3000 -> 3.85 / 3.57 / 3.58 / 3.60 / 3.62 ms
-int g_pipeline_max_n = 7000;                                         // gpk_debug_set key 14: pipelined only up to this order (with the split-K products, product + factorisation per step: order 6001 7.18 -> 6.50 ms, 7001 13.7 -> 13.6, 8501 22.3 -> 23.3, 10001 35.8 -> 38.6)
 
-// Block columns of the pipelined factorisation: a first block of g_pipeline_w0 columns (the chain can only start once its product is
-// there), then blocks of g_pipeline_ob columns; widths are multiples of the panel width, at most 512.
-int g_pipeline_w0 = 512, g_pipeline_ob = 512;                        // gpk_debug_set keys 28 / 29
+// Block columns of the pipelined factorisation: a first block of h->tune.pipeline_w0 columns (the chain can only start once its product is
+// there), then blocks of h->tune.pipeline_ob columns; widths are multiples of the panel width, at most 512.
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve = true);
-static std::vector<int> pipe_blocks(int nc) {
+static std::vector<int> pipe_blocks(gpk_handle h, int nc) {
     auto norm = [](int w) { w = (w / NB) * NB; return w < NB ? NB : (w > 512 ? 512 : w); };
     std::vector<int> b{0};
-    int w = norm(g_pipeline_w0);
-    while (b.back() < nc) { b.push_back(b.back() + w < nc ? b.back() + w : nc); w = norm(g_pipeline_ob); }
+    int w = norm(h->tune.pipeline_w0);
+    while (b.back() < nc) { b.push_back(b.back() + w < nc ? b.back() + w : nc); w = norm(h->tune.pipeline_ob); }
     return b;
 }
 
@@ -2201,7 +1423,7 @@ int gpk_i_pipe_streams(gpk_handle h) { return pipe_setup(h, 0, 0, false); }
 static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve) {
     // multiples of 32: bits 8k .. 8k+7 of the mask are one CU of shader engine k mod 4 on each of the 8 XCDs, so 32 bits take one CU from
     // every shader engine; other sizes leave the engines uneven (measured: 48 behaves like 32, 80 like 64)
-    int c = ((g_pipeline_chain_cus + 16) / 32) * 32;
+    int c = ((h->tune.pipeline_chain_cus + 16) / 32) * 32;
     if (c < 32) c = 32;
     if (c > h->num_cu - 32) c = h->num_cu - 32;
     if (!h->pipe_g || h->pipe_chain_cus != c) {
@@ -2228,16 +1450,16 @@ static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve) {
 }
 
 int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss) {
-    const int J = gpk_ceil_div(nc, 512) < 3 ? 0 : (int)pipe_blocks(nc).size() - 1;   // (orders below 1025: nothing to overlap)
+    const int J = gpk_ceil_div(nc, 512) < 3 ? 0 : (int)pipe_blocks(h, nc).size() - 1;   // (orders below 1025: nothing to overlap)
     h->pipe_tev_used = 0;
     h->prof_pipelined = 0;
     // (a handle on which the CU-masked streams could not be created -- a runtime or a container that does not allow CU masks --
     // silently keeps the one-stream schedule: same results, no overlap)
-    if (!h->pipe_unavailable && g_pipeline && J >= 3 && nc <= g_pipeline_max_n && h->num_cu >= 64 && pipe_setup(h, (g_pipeline_lookahead ? 4 : 2) * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0) != 0) {
+    if (!h->pipe_unavailable && h->tune.pipeline && J >= 3 && nc <= h->tune.pipeline_max_n && h->num_cu >= 64 && pipe_setup(h, (h->tune.pipeline_lookahead ? 4 : 2) * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0) != 0) {
         h->pipe_unavailable = true;
         (void)hipGetLastError();
     }
-    if (h->pipe_unavailable || !g_pipeline || J < 3 || nc > g_pipeline_max_n || h->num_cu < 64) {   // small systems: nothing to overlap; large: see above
+    if (h->pipe_unavailable || !h->tune.pipeline || J < 3 || nc > h->tune.pipeline_max_n || h->num_cu < 64) {   // small systems: nothing to overlap; large: see above
         if (h->prof) {
             while (h->pipe_tev.size() < 2) { hipEvent_t e; GPK_HIP(h, hipEventCreate(&e)); h->pipe_tev.push_back(e); }
             GPK_HIP(h, hipEventRecord(h->pipe_tev[0], h->stream));
@@ -2261,19 +1483,19 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
 // products: left-looking 512-column block updates on the GEMM partition, panel chains on the chain partition.
 static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int nc, int lead, double* Hb, int ldh, double* d_loss,
                            int pivot_base) {
-    const std::vector<int> bnd = pipe_blocks(nc);
+    const std::vector<int> bnd = pipe_blocks(h, nc);
     const int J = (int)bnd.size() - 1;
     if (J < 2) return potrf_seq(h, Hb, nc, ldh, pivot_base);
-    GPK_TRY(pipe_setup(h, (g_pipeline_lookahead ? 4 : 2) * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
+    GPK_TRY(pipe_setup(h, (h->tune.pipeline_lookahead ? 4 : 2) * (size_t)J + 1, h->prof ? 2 * (size_t)J : 0));
     const hipStream_t main_s = h->stream, G = h->pipe_g, C = h->pipe_c;
     // product of the blocks [jb, je): Hb[b_jb :, b_jb : b_je] = W[:, b_jb :]^T W[:, b_jb : b_je] (tiles above the diagonal skipped)
     auto product = [&](int jb, int je) {
         const int j0 = bnd[jb], j1 = bnd[je < J ? je : J];
-        // few tiles, long K: split K so that the launch has about g_pipeline_units workgroups (see GemmArgs::splitk)
-        const int th = g_pipeline_tile == 128 ? 128 : g_pipeline_tile == 64 ? 64 : 32;
+        // few tiles, long K: split K so that the launch has about h->tune.pipeline_units workgroups (see GemmArgs::splitk)
+        const int th = h->tune.pipeline_tile == 128 ? 128 : h->tune.pipeline_tile == 64 ? 64 : 32;
         const long tiles = (long)gpk_ceil_div(nc - j0, th) * gpk_ceil_div(j1 - j0, 64);
-        h->splitk_req = g_pipeline_units > 0 ? (int)((g_pipeline_units + tiles / 2) / tiles) : 0;
-        h->tile_req = jb > 0 ? g_pipeline_tile : 0;
+        h->splitk_req = h->tune.pipeline_units > 0 ? (int)((h->tune.pipeline_units + tiles / 2) / tiles) : 0;
+        h->tile_req = jb > 0 ? h->tune.pipeline_tile : 0;
         const int r = gpk_i_gemm(h, true, false, nc - j0, j1 - j0, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
                                  lead > j0 ? lead - j0 : 0, false, true);
         h->splitk_req = 0; h->tile_req = 0;
@@ -2311,7 +1533,7 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
     // block 0.  Measured at config 2 (phase time, ms): pre = 1 / 2 / 3 -> 4.01 / 4.16 / 4.37 with a 64-CU chain partition; with
     // the left-looking chain, pre = 1 and chain partitions of 16 / 24 / 32 / 40 / 64 CUs -> 4.65 / 4.06 / 3.88 / 3.98 / 4.10;
     // sequential (one stream, whole chip) 4.25.
-    int pre = g_pipeline_pre < 1 ? 1 : g_pipeline_pre;
+    int pre = h->tune.pipeline_pre < 1 ? 1 : h->tune.pipeline_pre;
     if (pre > J - 1) pre = J - 1;
     if (W) {
         rc = timed_product(main_s, 0, pre);
@@ -2329,7 +1551,7 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
             const double* Lrow = Hb + (long)j0 * ldh;                // rows j0.. of the factored panels, columns 0..j0
             if (j > 1) {                                             // panels 0..j-2: their chain finished an iteration ago
                 const long tiles = (long)gpk_ceil_div(m, 32) * gpk_ceil_div(ob, 64);
-                h->splitk_req = g_pipeline_units > 0 ? (int)((g_pipeline_units + tiles / 2) / tiles) : 0;
+                h->splitk_req = h->tune.pipeline_units > 0 ? (int)((h->tune.pipeline_units + tiles / 2) / tiles) : 0;
                 rc = gpk_i_gemm(h, false, true, m, ob, pb0, -1.0, Lrow, ldh, Lrow, ldh, 1.0, Hjj, ldh, false, 0, false, true);
                 h->splitk_req = 0;
                 if (rc) break;
@@ -2339,14 +1561,14 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
             // then into the other columns (ev_ready2, needed from the second panel on).  What lies between two block chains is
             // two event hops and one small rank-64 launch instead of a K = 512 product over the whole block column.
             const double* Lb = Lrow + pb0;
-            const int k1 = (g_pipeline_lookahead && pob > NB) ? pob - NB : 0;
+            const int k1 = (h->tune.pipeline_lookahead && pob > NB) ? pob - NB : 0;
             if (k1 > 0) {
                 PIPE_HIP(hipStreamWaitEvent(G, ev_pre[j - 1], 0));
                 rc = gpk_i_gemm(h, false, true, m, ob, k1, -1.0, Lb, ldh, Lb, ldh, 1.0, Hjj, ldh, false, 0, false, true);
                 if (rc) break;
             }
             PIPE_HIP(hipStreamWaitEvent(G, ev_chain[j - 1], 0));
-            if (g_pipeline_lookahead) {
+            if (h->tune.pipeline_lookahead) {
                 const int w0 = ob < NB ? ob : NB;
                 rc = gpk_i_gemm(h, false, true, m, w0, pob - k1, -1.0, Lb + k1, ldh, Lb + k1, ldh, 1.0, Hjj, ldh, false);
                 if (rc) break;
@@ -2361,7 +1583,7 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
                 if (rc) break;
             }
         }
-        if (j == 0 || !g_pipeline_lookahead) PIPE_HIP(hipEventRecord(ev_ready[j], G));
+        if (j == 0 || !h->tune.pipeline_lookahead) PIPE_HIP(hipEventRecord(ev_ready[j], G));
         if (W && j + pre < J) {                                      // product of the block `pre` ahead, while the chain of block j runs
             rc = timed_product(G, j + pre, j + pre + 1);
             if (rc) break;
@@ -2369,8 +1591,8 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
         h->stream = C;
         h->no_sk = 1;                                                // (the tile-list workspace belongs to the GEMM stream while both run)
         PIPE_HIP(hipStreamWaitEvent(C, ev_ready[j], 0));
-        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, pivot_base + j0, g_left_looking_panels != 0,
-                               (g_pipeline_lookahead && j > 0) ? ev_ready2[j] : nullptr, (g_pipeline_lookahead && j + 1 < J && ob > NB) ? ev_pre[j] : nullptr);
+        rc = gpk_i_potrf_panel(h, Hjj, m, ob, ldh, pivot_base + j0, h->tune.left_looking_panels != 0,
+                               (h->tune.pipeline_lookahead && j > 0) ? ev_ready2[j] : nullptr, (h->tune.pipeline_lookahead && j + 1 < J && ob > NB) ? ev_pre[j] : nullptr);
         h->no_sk = 0;
         if (rc) break;
         PIPE_HIP(hipEventRecord(ev_chain[j], C));
@@ -2386,13 +1608,11 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
     return 0;
 }
 
-int g_probe_chain_cus = 0;                                           // gpk_debug_set key 11: overlap probe with a CU-mask partition
-int g_fused_trsv = 1;                                                 // gpk_debug_set key 4: 0 = two launches per block, 1 = fused with data-tagged hand-offs (round 3), 2 = fused with flags (round 1)
 
 int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double* x) {
     if (n <= 0) return 0;
     const int nblk = gpk_ceil_div(n, NB);
-    if (g_fused_trsv == 1 && nblk <= GPK_MAX_TRSV_BLOCKS) {     // data-tagged hand-offs (default)
+    if (h->tune.fused_trsv == 1 && nblk <= GPK_MAX_TRSV_BLOCKS) {     // data-tagged hand-offs (default)
         if (!h->d_trsv_gran) GPK_HIP(h, hipMalloc(&h->d_trsv_gran, (size_t)GPK_MAX_TRSV_BLOCKS * NB * sizeof(TrsvGran)));
         if (h->trsv_gran_epoch == 0) GPK_HIP(h, hipMemsetAsync(h->d_trsv_gran, 0, (size_t)GPK_MAX_TRSV_BLOCKS * NB * sizeof(TrsvGran), h->stream));
         const long long ep = ++h->trsv_gran_epoch;
@@ -2401,7 +1621,8 @@ int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-    if (g_fused_trsv && nblk <= GPK_MAX_TRSV_BLOCKS) {
+#ifdef GPK_DEV                                                       // retired variant (dev/gpk_factor_retired.inc): the flag-chained form of round 1
+    if (h->tune.fused_trsv && nblk <= GPK_MAX_TRSV_BLOCKS) {
         if (++h->trsv_epoch == 0x7fffffff) {                         // epoch wrap: clear the flags once every 2^31 solves
             GPK_HIP(h, hipMemsetAsync(h->d_flags, 0, GPK_MAX_TRSV_BLOCKS * sizeof(int), h->stream));
             h->trsv_epoch = 1;
@@ -2411,6 +1632,7 @@ int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
+#endif
     if (!trans) {
         for (int b = 0; b < nblk; ++b) {
             const int r0 = b * NB, nb = (n - r0 < NB) ? n - r0 : NB;
@@ -2438,34 +1660,7 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------
-extern "C" int gpk_debug_set_mt_trsm(int v) { g_mt_trsm = v; return 0; }
-extern "C" int gpk_debug_set_strip(int v) { g_strip = v; return 0; }
-extern "C" int gpk_debug_set_fused_trsv(int v) { g_fused_trsv = v; return 0; }
-extern "C" int gpk_debug_set_panel_unrolled(int v) { g_panel_unrolled = v; return 0; }
-extern "C" int gpk_debug_set_fused_panel(int v) { g_fused_panel = v; return 0; }
-extern "C" int gpk_debug_set_persistent_ob(int v) { g_persistent_ob = v; return 0; }
-extern "C" int gpk_debug_set_probe_chain_cus(int v) { g_probe_chain_cus = v; return 0; }
-extern "C" int gpk_debug_set_pipeline(int v) { g_pipeline = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_chain_cus(int v) { g_pipeline_chain_cus = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_max_n(int v) { g_pipeline_max_n = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_widths(int key, int v) { (key == 28 ? g_pipeline_w0 : g_pipeline_ob) = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_tile(int v) { g_pipeline_tile = v; return 0; }
-extern "C" int gpk_debug_set_solve_splitk(int v) { g_solve_splitk = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_lookahead(int v) { g_pipeline_lookahead = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_units(int v) { g_pipeline_units = v; return 0; }
-extern "C" int gpk_debug_set_pipeline_pre(int v) { g_pipeline_pre = v; return 0; }
-extern "C" int gpk_debug_set_left_looking_panels(int v) { g_left_looking_panels = v; return 0; }
-extern "C" int gpk_debug_set_panel_mfma(int v) { g_panel_mfma = v; return 0; }
-extern "C" int gpk_debug_set_panel_fused(int v) { g_panel_fused = v; return 0; }
-extern "C" int gpk_debug_set_potrf_ob(int v) { g_potrf_ob = v; return 0; }
-extern "C" int gpk_debug_set_potrf_pipeline(int key, int v) { (key == 19 ? g_potrf_pipeline_min_n : g_potrf_pipeline_max_n) = v; return 0; }
 
-extern "C" int gpk_debug_stamps(gpk_handle h, unsigned long long* host16, int enable) {
-    if (!h) return GPK_ERR_ARG;
-    g_dbg = enable;
-    if (host16) GPK_HIP(h, hipMemcpyFromSymbol(host16, HIP_SYMBOL(gpk_dbg_stamps), 16 * sizeof(unsigned long long)));
-    return 0;
-}
 
 extern "C" int gpk_potrf(gpk_handle h, double* A, int n, int lda, int* host_info) {
     if (!h || !A || n < 0 || lda < n) return GPK_ERR_ARG;
@@ -2544,56 +1739,6 @@ extern "C" int gpk_potrs(gpk_handle h, const double* L, int n, int ldl, double* 
     return gpk_trsm(h, 1, L, n, ldl, B, nrhs, ldb);
 }
 
-// development probe: does a big GEMM on a low-priority side stream hide behind the latency-bound Cholesky panel chain?
-// Runs  C2 <- S^T S  (n x n, k rows) on a side stream while  potrf(H)  runs on the handle's stream; returns the three
-// times in ms: potrf alone, syrk alone, both concurrently (wall).
-extern "C" int gpk_debug_overlap_probe(gpk_handle h, double* H, int n, int ldh, const double* S, int k, int lds, double* C2, int ldc,
-                                       double* host_ms3) {
-    if (!h || !H || !S || !C2 || !host_ms3) return GPK_ERR_ARG;
-    hipStream_t side = nullptr, main_s = h->stream, chain = nullptr;
-    const hipStream_t restore = h->stream;
-    int lo = 0, hi = 0;
-    GPK_HIP(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (g_probe_chain_cus > 0) {
-        // spatial partition: the chain (potrf) stream gets the first g_probe_chain_cus bits of the CU mask (bit i -> XCD i % 8 on
-        // this chip, so a multiple of 8 takes the same number of CUs from every XCD), the GEMM stream gets the rest
-        uint32_t ma[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mb[8];
-        for (int i = 0; i < g_probe_chain_cus && i < 256; ++i) ma[i >> 5] |= 1u << (i & 31);
-        for (int i = 0; i < 8; ++i) mb[i] = ~ma[i];
-        GPK_HIP(h, hipExtStreamCreateWithCUMask(&chain, 8, ma));
-        GPK_HIP(h, hipExtStreamCreateWithCUMask(&side, 8, mb));
-        main_s = chain;
-        h->stream = chain;
-    } else
-    GPK_HIP(h, hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
-    hipEvent_t e0, e1, ef;
-    GPK_HIP(h, hipEventCreate(&e0)); GPK_HIP(h, hipEventCreate(&e1)); GPK_HIP(h, hipEventCreateWithFlags(&ef, hipEventDisableTiming));
-    double* Hc = nullptr;
-    GPK_HIP(h, hipMalloc((void**)&Hc, (size_t)n * ldh * sizeof(double)));
-    float ms = 0.f;
-    for (int mode = 0; mode < 3; ++mode) {
-        GPK_HIP(h, hipMemcpyAsync(Hc, H, (size_t)n * ldh * sizeof(double), hipMemcpyDeviceToDevice, main_s));
-        GPK_HIP(h, hipStreamSynchronize(main_s));
-        GPK_HIP(h, hipEventRecord(e0, main_s));
-        if (mode == 1 || mode == 2) {
-            GPK_HIP(h, hipStreamWaitEvent(side, e0, 0));
-            h->stream = side;
-            int rc = gpk_i_gemm(h, true, false, n, n, k, 1.0, S, lds, S, lds, 0.0, C2, ldc, true);
-            h->stream = main_s;
-            if (rc) return rc;
-            GPK_HIP(h, hipEventRecord(ef, side));
-        }
-        if (mode == 0 || mode == 2) GPK_TRY(gpk_i_potrf(h, Hc, n, ldh, 0));
-        if (mode == 1 || mode == 2) GPK_HIP(h, hipStreamWaitEvent(main_s, ef, 0));
-        GPK_HIP(h, hipEventRecord(e1, main_s));
-        GPK_HIP(h, hipEventSynchronize(e1));
-        GPK_HIP(h, hipEventElapsedTime(&ms, e0, e1));
-        host_ms3[mode] = ms;
-    }
-    GPK_HIP(h, hipFree(Hc));
-    h->stream = restore;
-    if (chain) GPK_HIP(h, hipStreamDestroy(chain));
-    GPK_HIP(h, hipStreamDestroy(side));
-    GPK_HIP(h, hipEventDestroy(e0)); GPK_HIP(h, hipEventDestroy(e1)); GPK_HIP(h, hipEventDestroy(ef));
-    return 0;
-}
+#ifdef GPK_DEV
+#include "dev/gpk_factor_dev_abi.inc"    // gpk_debug_stamps, gpk_debug_overlap_probe (include/gpk_dev.h): development build only
+#endif

@@ -135,17 +135,6 @@ __device__ __forceinline__ double lds_at(const double* __restrict__ lds, int x, 
 }
 
 constexpr int SG_H = 8, SG_W = 4;                                    // supertile: 8 tile rows x 4 tile columns
-int g_gemm_extra_lds = 0;                                            // gpk_debug_set key 9: bytes of dynamic LDS requested on top (occupancy throttle for overlap experiments)
-int g_k64_small = 1;                                                 // gpk_debug_set key 8: 0 = 64-row tiles only in the K <= 64 kernel
-int g_band_mb = 192;                                                 // gpk_debug_set key 35: MB of A per band of a tall leading-zero launch (0 = no bands).  North-star size, solve phase: no bands 45.2 ms, 48 MB 44.9, 96 MB 43.2, 192 MB 42.6-43.1, 288 MB 43.9, 400 MB 45.4
-int g_syrk_band = 256;                                               // gpk_debug_set key 36: MB of S per band of a large leading-zero SYRK launch (0 = column-major over all rows).  North-star size, the product S^T S: no bands 24.15 ms, 192 MB 23.4, 256 MB 22.9, 384 MB 23.55, 512 MB 24.3
-int g_big_min = 6000;                                                 // gpk_debug_set key 38: launches with at least this many 64 x 64 tiles use the 128 x 128 tile with 16 waves, one workgroup per CU (0 = never).  tools/gemm_big_probe.py, 64 x 64 -> 128 x 64 -> this: NN 10500^3 60.0 / 58.6 / 65.2 TF/s, 8192^3 62.2 / 60.9 / 69.1 on a slow box; north-star solve phase 44.6 -> 43.7 ms with thresholds 3000 .. 6000; at config 2 (threshold 2000) the solve phase loses 5 %
-int g_big_lower_min = 8000;                                          // gpk_debug_set key 50: lower-triangular leading-zero launches (S^T S) with at least this many lower 64 x 64 tiles use the 128 x 128 / 16-wave tile (0 = never)
-int g_tall_min = 1500;                                               // gpk_debug_set key 33: launches with at least this many 64 x 64 tiles use the 128 x 64 / 8-wave tile (0 = never).  Measured (tools/gemm_big_probe.py, 64 x 64 -> 128 x 64): NN 10500^3 64.5 -> 67.9 TF/s, TN 4001^2 x 8400 61.3 -> 66.4, NN 2048 x 16001 x 2048 61.2 -> 65.0, 8192^3 68.6 -> 69.2; in the solve phase at config 2 the 1568-tile update 397 -> 352 us, the 3276-tile one -2 %, the 1260-tile one +10 % (hence the threshold); north-star size: solve 46.0 -> 44.7 ms
-int g_force_splitk = 0;                                              // gpk_debug_set key 25: split K of every eligible gpk_gemm launch into this many chunks (tests)
-int g_rev_k = 0;                                                     // gpk_debug_set key 16
-int g_stagger = 0;                                                   // gpk_debug_set key 15: start-time stagger of co-resident GEMM workgroups (experiment)
-int g_supertile = 0;                                                 // gpk_debug_set key 6: 1 = supertile schedule for the leading-zero SYRK (below)
 
 __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm, int& tn) {
     if (g.nsuper > 0) {
@@ -236,7 +225,7 @@ __device__ __forceinline__ bool map_tile(const GemmArgs& g, const int b, int& tm
             // from memory once per row instead of once per tile; the few column panels of B (ntn x K x 64 doubles) are what is
             // re-read, and they fit the Infinity Cache.  For the 512-column products of the pipelined phase (ntn = 8, see
             // gpk_factor.hip): column-major order re-reads the 269 MB of S eight times per product.  EXPERIMENT, off by default: measured
-            // slower (see g_row_order).
+            // slower (see h->tune.row_order).
             const int nwg2 = g.ntiles, xcd2 = b & 7, q2 = nwg2 >> 3, r2 = nwg2 & 7;
             const int l2 = (xcd2 < r2 ? xcd2 * (q2 + 1) : r2 * (q2 + 1) + (xcd2 - r2) * q2) + (b >> 3);
             tm = l2 / g.ntn;
@@ -679,18 +668,12 @@ int launch_k64(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     // a rank-64 update is one round trip to memory plus 64 MFMAs per wave of a 64 x 64 tile: with fewer than ~4 tiles per
     // CU, halving the tile spreads the MFMA phase over twice as many workgroups
     const long t64 = (long)gpk_ceil_div(g.M, 64) * gpk_ceil_div(g.N, 64);
-    if (g_k64_small && t64 < 4 * h->num_cu && g.M > 64) return launch_k64_bm<32>(h, ta, tb, g);
+    if (h->tune.k64_small && t64 < 4 * h->num_cu && g.M > 64) return launch_k64_bm<32>(h, ta, tb, g);
     return launch_k64_bm<64>(h, ta, tb, g);
 }
 
 
 // ---- tile-list ("stream-K") plans: built on the host per launch SHAPE, cached on the device ------------------------------------
-int g_sk = 1;                                                        // gpk_debug_set key 42: 0 = never, 1 = automatic, 2 = every eligible launch
-int g_sk_rounds = 6;                                                 // gpk_debug_set key 43: automatic mode uses tile lists for launches of fewer than this many rounds of resident workgroups
-int g_sk_stagger = 2;                                                // gpk_debug_set key 45: start stagger of the co-resident workgroups of a tile-list launch (slot x this x 512 cycles; every workgroup starts at once and has the same amount of work -- without it the four workgroups of a CU run in lock-step, see the kernel)
-int g_sk_rowclass = 1;                                               // gpk_debug_set key 46: 0 = keep the launch's tile order when cutting shares (experiment)
-int g_row_order = 0;                                                 // gpk_debug_set key 49: 1 = row-major, per-XCD-contiguous tile order for the narrow leading-zero products of the pipelined phase (experiment, round 3: fewer re-reads of S by construction, but slower -- sum of the product launches 2.14 -> 2.31 ms, phase 3.20 -> 3.39 ms at config 2, tools/row_order_ab.sh: longest-column-first matters more than the traffic)
-int g_sk_snap = 4;                                                   // gpk_debug_set key 44: a share boundary closer than this many slabs to a tile boundary moves there
 
 struct SkKey {
     int bm, bn, M, N, K, lower, lead, lead_div, tri, skip_upper, band, G;
@@ -761,14 +744,14 @@ void sk_enumerate(const GemmArgs& g, std::vector<SkTile>& out) {
 }
 
 template <int BM, int BN>
-SkPlan* sk_build(const GemmArgs& g, int G, const SkKey& key) {
+SkPlan* sk_build(gpk_handle h, const GemmArgs& g, int G, const SkKey& key) {
     std::vector<SkTile> tiles;
     sk_enumerate<BM, BN>(g, tiles);
     // Row tiles stay with "their" XCD, as in the one-tile-per-workgroup order (consecutive blocks = consecutive row tiles of a column,
     // block b on XCD b % 8): the shares are handed to the XCDs in contiguous runs (below), so the tile sequence is regrouped by
     // tm mod 8 first -- every XCD then works on 1/8 of the rows of A, which stay in ITS L2 while it sweeps the columns.  (Without
     // this every XCD streamed all of A: the update launches of the solve phase ran 1.3 - 2.5x slower than one tile per workgroup.)
-    if (g_sk_rowclass) std::stable_sort(tiles.begin(), tiles.end(), [](const SkTile& a, const SkTile& b) { return (a.tm & 7) < (b.tm & 7); });
+    if (h->tune.sk_rowclass) std::stable_sort(tiles.begin(), tiles.end(), [](const SkTile& a, const SkTile& b) { return (a.tm & 7) < (b.tm & 7); });
     long total = 0;
     for (const SkTile& t : tiles) total += t.k1 - t.k0;
     if (tiles.empty() || total <= 0) return nullptr;
@@ -786,8 +769,8 @@ SkPlan* sk_build(const GemmArgs& g, int G, const SkKey& key) {
         if (w == 0) b = 0;
         if (w == G) b = total;
         while (ti + 1 < pre.size() && pre[ti + 1] <= b) ++ti;        // pre[ti] <= b < pre[ti + 1] (or the end)
-        if (b - pre[ti] < g_sk_snap) b = pre[ti];
-        else if (ti + 1 < pre.size() && pre[ti + 1] - b < g_sk_snap) b = pre[ti + 1];
+        if (b - pre[ti] < h->tune.sk_snap) b = pre[ti];
+        else if (ti + 1 < pre.size() && pre[ti + 1] - b < h->tune.sk_snap) b = pre[ti + 1];
         if (w > 0 && b < bnd[w - 1]) b = bnd[w - 1];
         bnd[w] = b;
     }
@@ -881,7 +864,7 @@ SkPlan* sk_plan_for(gpk_handle h, const GemmArgs& g, int G) {
     key.bm = BM; key.bn = BN; key.M = g.M; key.N = g.N; key.K = g.K; key.lower = g.lower_only; key.lead = g.lead; key.lead_div = g.lead_div;
     key.tri = g.tri_a; key.skip_upper = g.skip_upper; key.band = g.band; key.G = G;
     for (SkPlan* p : c->plans) if (p->key == key) { p->stamp = ++c->clock; return p->nblocks > 0 ? p : nullptr; }
-    SkPlan* p = sk_build<BM, BN>(g, G, key);
+    SkPlan* p = sk_build<BM, BN>(h, g, G, key);
     if (!p) { p = new SkPlan(); p->key = key; }                       // remembered as "not worth it"
     else if ((size_t)p->nslots * BM * BN * sizeof(double) > h->splitk_ws_cap || p->ntickets > h->splitk_cnt_cap || sk_upload(h, c, p) != 0) {
         p->nblocks = 0;
@@ -902,30 +885,30 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
     g.nsuper = 0;
     prof_count(h, g, BM, BN);
     int nblocks = g.ntiles;
-    if (g.lower_only && g.lead > 0 && g_supertile && g.lead_div == 1 && g.stair.nseg == 0) {
+    if (g.lower_only && g.lead > 0 && h->tune.supertile && g.lead_div == 1 && g.stair.nseg == 0) {
         const int T = g.ntm, ncg = gpk_ceil_div(T, SG_W);
         for (int cg = 0; cg < ncg; ++cg) g.nsuper += gpk_ceil_div(T - cg * SG_W, SG_H);
         nblocks = 8 * gpk_ceil_div(g.nsuper, 8) * SG_H * SG_W;
     }
     g.band = 0;
-    g.row_order = (g_row_order && g.lead > 0 && !g.lower_only && !g.tri_a && g.skip_upper && g.ntn <= 16) ? 1 : 0;
-    if (g.lead > 0 && g.lower_only && g_syrk_band > 0) {
+    g.row_order = (h->tune.row_order && g.lead > 0 && !g.lower_only && !g.tri_a && g.skip_upper && g.ntn <= 16) ? 1 : 0;
+    if (g.lead > 0 && g.lower_only && h->tune.syrk_band > 0) {
         const double panel = (double)BM * g.K * sizeof(double);       // one column panel of S
-        if ((double)g.ntm * panel > 4.0 * g_syrk_band * 1048576.0) {
-            int r = (int)(g_syrk_band * 1048576.0 / panel);
+        if ((double)g.ntm * panel > 4.0 * h->tune.syrk_band * 1048576.0) {
+            int r = (int)(h->tune.syrk_band * 1048576.0 / panel);
             g.band = r < 2 ? 2 : r;
         }
     }
-    if (g.lead > 0 && !g.lower_only && !g.tri_a && g_band_mb > 0) {
+    if (g.lead > 0 && !g.lower_only && !g.tri_a && h->tune.band_mb > 0) {
         const double panel = (double)BM * g.K * sizeof(double);       // one row tile's rows of A
-        if ((double)g.ntm * panel > 2.0 * g_band_mb * 1048576.0) {
-            int r = (int)(g_band_mb * 1048576.0 / panel);
+        if ((double)g.ntm * panel > 2.0 * h->tune.band_mb * 1048576.0) {
+            int r = (int)(h->tune.band_mb * 1048576.0 / panel);
             g.band = r < 1 ? 1 : r;
         }
     }
     g.splitk = 1; g.ws = nullptr; g.cnt = nullptr;
     int want = h->splitk_req;
-    if (want <= 1 && g_force_splitk > 1 && gpk_i_splitk_reserve(h) == 0) want = g_force_splitk;
+    if (want <= 1 && h->tune.force_splitk > 1 && gpk_i_splitk_reserve(h) == 0) want = h->tune.force_splitk;
     if (want > 1 && !g.lower_only && !g.tri_a && h->d_splitk_ws && h->d_splitk_cnt) {
         int s = want > 16 ? 16 : want;
         while (s > 1 && (g.K / BK) / s < 16) --s;                    // chunks of at least 16 slabs
@@ -936,12 +919,12 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         }
     }
     dim3 grid(nblocks), block((BM / WM) * (BN / WN) * 64);
-    const size_t dyn = (size_t)g_gemm_extra_lds;
+    const size_t dyn = (size_t)h->tune.gemm_extra_lds;
     g.sk_segs = nullptr; g.sk_off = nullptr;
     // Tile-list launch?  Resident workgroup slots of this configuration (waves per workgroup -> workgroups per CU: 4 waves 4 (5 for the
     // 32-row tile), 8 waves 2, 16 waves 1); worth it when the launch is only a few rounds of them -- then the last, partly filled
     // round and the spread of tile lengths (leading zeros, triangular operand) cost a large share of its time.
-    if (g_sk && g.splitk == 1 && g.nsuper == 0 && !h->no_sk && !g.rev_k && g.K >= 4 * BK && h->num_cu >= 8 && g.stair.nseg == 0) {
+    if (h->tune.sk && g.splitk == 1 && g.nsuper == 0 && !h->no_sk && !g.rev_k && g.K >= 4 * BK && h->num_cu >= 8 && g.stair.nseg == 0) {
         constexpr int WAVES = (BM / WM) * (BN / WN);
         const int per_cu = WAVES >= 16 ? 1 : WAVES >= 8 ? 2 : (BM == 32 ? 5 : 4);
         const int G = ((h->num_cu * per_cu) / 8) * 8;
@@ -953,11 +936,11 @@ int launch_cfg(gpk_handle h, bool ta, bool tb, GemmArgs& g) {
         // for the triangular products).  On plain products whose tile count is not a whole number of rounds the lists gain 12-21 %
         // (tools/sk_probe.py: 1056 tiles 0.375 -> 0.329 ms, 2080 tiles 0.69 -> 0.61 ms), at whole rounds they are neutral.
         const bool plain = g.lead == 0 && !g.tri_a && !g.lower_only && !g.skip_upper;
-        if ((g_sk == 2 || (plain && g.K >= 64 * BK && eff < (long)g_sk_rounds * G && eff % G > G / 16 && eff % G < G - G / 4)) && gpk_i_splitk_reserve(h) == 0) {
+        if ((h->tune.sk == 2 || (plain && g.K >= 64 * BK && eff < (long)h->tune.sk_rounds * G && eff % G > G / 16 && eff % G < G - G / 4)) && gpk_i_splitk_reserve(h) == 0) {
             SkPlan* p = sk_plan_for<BM, BN>(h, g, G);
             if (p) {
                 g.sk_segs = p->d_segs; g.sk_off = p->d_off; g.ws = h->d_splitk_ws; g.cnt = h->d_splitk_cnt;
-                if (g_sk_stagger > 0) g.stagger = g_sk_stagger;
+                if (h->tune.sk_stagger > 0) g.stagger = h->tune.sk_stagger;
                 dim3 sgrid(p->nblocks);
                 if (g.tri_a) gemm_f64_kernel<BM, BN, WM, WN, false, false, true, true><<<sgrid, block, dyn, h->stream>>>(g);
                 else if (!ta && !tb) gemm_f64_kernel<BM, BN, WM, WN, false, false, false, true><<<sgrid, block, dyn, h->stream>>>(g);
@@ -992,79 +975,8 @@ __global__ void tril_kernel(double* A, int n, long lda) {
 
 }  // namespace
 
-static int g_force_cfg = 0;          // development aid (gpk_debug_set key 0): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
 
-extern "C" int gpk_debug_set_mt_trsm(int v);
-extern "C" int gpk_debug_set_strip(int v);
-extern "C" int gpk_debug_set_fused_trsv(int v);
-extern "C" int gpk_debug_set_fused_panel(int v);
-extern "C" int gpk_debug_set_panel_unrolled(int v);
-extern "C" int gpk_debug_set_persistent_ob(int v);
-extern "C" int gpk_debug_set_use_dinv(int v);
-extern "C" int gpk_debug_set_eikonal_lz(int v);
-extern "C" int gpk_debug_set_probe_chain_cus(int v);
-extern "C" int gpk_debug_set_pipeline(int v);
-extern "C" int gpk_debug_set_pipeline_chain_cus(int v);
-extern "C" int gpk_debug_set_pipeline_max_n(int v);
-extern "C" int gpk_debug_set_pipeline_pre(int v);
-extern "C" int gpk_debug_set_pipeline_units(int v);
-extern "C" int gpk_debug_set_pipeline_lookahead(int v);
-extern "C" int gpk_debug_set_solve_splitk(int v);
-extern "C" int gpk_debug_set_pipeline_tile(int v);
-extern "C" int gpk_debug_set_structured(int v);
-extern "C" int gpk_debug_set_pipeline_widths(int key, int v);
-extern "C" int gpk_debug_set_left_looking_panels(int v);
-extern "C" int gpk_debug_set_potrf_pipeline(int key, int v);
-extern "C" int gpk_debug_set_panel_mfma(int v);
-extern "C" int gpk_debug_set_panel_fused(int v);
-extern "C" int gpk_debug_set_potrf_ob(int v);
 
-extern "C" int gpk_debug_set(int key, int value) {
-    if (key == 0) { g_force_cfg = value; return 0; }
-    if (key == 2) return gpk_debug_set_mt_trsm(value);
-    if (key == 3) return gpk_debug_set_strip(value);
-    if (key == 4) return gpk_debug_set_fused_trsv(value);
-    if (key == 5) return gpk_debug_set_fused_panel(value);
-    if (key == 41) return gpk_debug_set_panel_unrolled(value);
-    if (key == 7) return gpk_debug_set_persistent_ob(value);
-    if (key == 8) { g_k64_small = value; return 0; }
-    if (key == 9) { g_gemm_extra_lds = value; return 0; }
-    if (key == 6) { g_supertile = value; return 0; }
-    if (key == 10) return gpk_debug_set_use_dinv(value);
-    if (key == 23) return gpk_debug_set_eikonal_lz(value);
-    if (key == 11) return gpk_debug_set_probe_chain_cus(value);
-    if (key == 12) return gpk_debug_set_pipeline(value);
-    if (key == 13) return gpk_debug_set_pipeline_chain_cus(value);
-    if (key == 14) return gpk_debug_set_pipeline_max_n(value);
-    if (key == 15) { g_stagger = value; return 0; }
-    if (key == 17) return gpk_debug_set_pipeline_pre(value);
-    if (key == 24) return gpk_debug_set_pipeline_units(value);
-    if (key == 26) return gpk_debug_set_pipeline_lookahead(value);
-    if (key == 30) return gpk_debug_set_solve_splitk(value);
-    if (key == 34) return gpk_debug_set_pipeline_tile(value);
-    if (key == 40) return gpk_debug_set_structured(value);
-    if (key == 28 || key == 29) return gpk_debug_set_pipeline_widths(key, value);
-    if (key == 18) return gpk_debug_set_left_looking_panels(value);
-    if (key == 19 || key == 20) return gpk_debug_set_potrf_pipeline(key, value);
-    if (key == 21) return gpk_debug_set_panel_mfma(value);
-    if (key == 48) return gpk_debug_set_panel_fused(value);
-    if (key == 51) return gpk_debug_set_potrf_ob(value);
-    if (key == 16) { g_rev_k = value; return 0; }
-    if (key == 25) { g_force_splitk = value; return 0; }
-    if (key == 33) { g_tall_min = value; return 0; }
-    if (key == 35) { g_band_mb = value; return 0; }
-    if (key == 38) { g_big_min = value; return 0; }
-    if (key == 36) { g_syrk_band = value; return 0; }
-    if (key == 42) { g_sk = value; return 0; }
-    if (key == 43) { g_sk_rounds = value; return 0; }
-    if (key == 44) { g_sk_snap = value; return 0; }
-    if (key == 45) { g_sk_stagger = value; return 0; }
-    if (key == 46) { g_sk_rowclass = value; return 0; }
-    if (key == 47) { extern int g_asm_pairs; g_asm_pairs = value; return 0; }
-    if (key == 49) { g_row_order = value; return 0; }
-    if (key == 50) { g_big_lower_min = value; return 0; }
-    return GPK_ERR_ARG;
-}
 
 void gpk_i_sk_free(gpk_handle h) {
     SkCache* c = (SkCache*)h->sk_cache;
@@ -1090,27 +1002,27 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     if (g.lead > 0 && h->stair.nseg > 0) { g.stair = h->stair; g.stair_col0 = h->stair_col0; g.stair_row0 = h->stair_row0; }
     g.tri_a = (tri_a && !ta && !tb && !lower_only) ? 1 : 0;
     g.skip_upper = (skip_upper && !lower_only) ? 1 : 0;
-    g.stagger = g_stagger;
+    g.stagger = h->tune.stagger;
     g.band = 0; g.splitk = 1; g.ws = nullptr; g.cnt = nullptr; g.nsuper = 0; g.ntm_full = 0;   // (set per launch configuration below)
     g.sk_segs = nullptr; g.sk_off = nullptr; g.row_order = 0;
-    g.rev_k = (g_rev_k && g.lead > 0) ? 1 : 0;
+    g.rev_k = (h->tune.rev_k && g.lead > 0) ? 1 : 0;
     g.vecA = ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
     g.vecB = ((ldb & 1) == 0) && (((uintptr_t)B & 15) == 0);
-    if (k <= 64 && !lower_only && !g.tri_a && !g.skip_upper && g_force_cfg == 0 &&
+    if (k <= 64 && !lower_only && !g.tri_a && !g.skip_upper && h->tune.force_cfg == 0 &&
         (beta == 0.0 || (beta == 1.0 && (alpha == 1.0 || alpha == -1.0))))
         return launch_k64(h, ta, tb, g);
     // The 64x64 configuration (4 workgroups per CU, two slabs in flight) is used for every shape: with the straight-line
     // two-slab prefetch it beats the 128x128 one (2 per CU, 232 VGPRs, one slab in flight) from 2048 to 21000 on every
     // operand layout (tools/gemm_big_probe.py: 62.0 vs 58.8 TF/s NN 10500^3-ish, 58.6 vs 49.8 NT K=512).  The large
     // tiles stay reachable through gpk_debug_set(0, 1) as the reference point for a register-leaner rewrite.
-    const bool big = (g_force_cfg == 1) && !g.tri_a;
+    const bool big = (h->tune.force_cfg == 1) && !g.tri_a;
     if (big) return launch_cfg<128, 128, 64, 64>(h, ta, tb, g);
     // (lower-triangular output with leading zeros = the product S^T S: from ~8000 lower 64 x 64 tiles on -- n_z ~ 8000 -- the 128 x 128 tile's
     // halved operand traffic wins: north-star size 23.9 -> 22.2 ms; at config 2, 2016 tiles, it loses: 1.59 -> 2.07 ms)
-    const bool big_lower = lower_only && g.lead > 0 && g_force_cfg == 0 && g_big_lower_min > 0 && (long)gpk_ceil_div(m, 64) * (gpk_ceil_div(m, 64) + 1) / 2 >= g_big_lower_min;
-    if ((g_force_cfg == 4 || big_lower || (g_force_cfg == 0 && g_big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_big_min)) && !g.tri_a && (!lower_only || g_force_cfg == 4 || big_lower))
+    const bool big_lower = lower_only && g.lead > 0 && h->tune.force_cfg == 0 && h->tune.big_lower_min > 0 && (long)gpk_ceil_div(m, 64) * (gpk_ceil_div(m, 64) + 1) / 2 >= h->tune.big_lower_min;
+    if ((h->tune.force_cfg == 4 || big_lower || (h->tune.force_cfg == 0 && h->tune.big_min > 0 && k > 64 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= h->tune.big_min)) && !g.tri_a && (!lower_only || h->tune.force_cfg == 4 || big_lower))
         return launch_cfg<128, 128, 32, 32>(h, ta, tb, g);           // 16 waves, one workgroup per CU
-    if ((g_force_cfg == 3 || (g_force_cfg == 0 && g_tall_min > 0 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= g_tall_min)) && !g.tri_a && !lower_only)
+    if ((h->tune.force_cfg == 3 || (h->tune.force_cfg == 0 && h->tune.tall_min > 0 && (long)gpk_ceil_div(m, 64) * gpk_ceil_div(n, 64) >= h->tune.tall_min)) && !g.tri_a && !lower_only)
         return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);            // 8 waves, 2 workgroups per CU
     // short-and-wide updates of the triangular-solve recursion (M = 256 or 512 against ~4000 columns): 64x64 tiles give
     // only 1-2 workgroups per CU, i.e. one wave per SIMD and nothing to hide latency behind; 32x64 tiles double that
@@ -1118,8 +1030,8 @@ int gpk_i_gemm(gpk_handle h, bool ta, bool tb, int m, int n, int k, double alpha
     if (g.tri_a) t64 /= 2;                                            // workgroups handle pairs of row tiles
     // (also for long K: restricting this to K <= 1024 was measured slower on the 512-column products of the pipelined SYRK and on
     // the mid-size updates of the triangular solve -- 504 tiles of 64x64 leave the CUs at 2-3 workgroups)
-    if (g_force_cfg == 0 && h->tile_req == 128 && !lower_only && !g.tri_a) return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);
-    if (g_force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64 && h->tile_req != 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
+    if (h->tune.force_cfg == 0 && h->tile_req == 128 && !lower_only && !g.tri_a) return launch_cfg<128, 64, 32, 32>(h, ta, tb, g);
+    if (h->tune.force_cfg == 0 && !lower_only && t64 < 2 * h->num_cu && m >= 64 && h->tile_req != 64) return launch_cfg<32, 64, 16, 32>(h, ta, tb, g);
     // (A "round model" -- co-resident workgroups start and finish together, a partly filled last round costs at least half a round, so
     // e.g. 1260 tiles of 64 rows should lose against 2457 tiles of 32 rows -- was tried as the selector and is wrong for this kernel:
     // 383 -> 420 us for that launch, 1384 -> 1477 us for the 3276-tile one; only launches below 0.6 rounds gained, 121 -> 105 us.)

@@ -207,8 +207,6 @@ int check_prob(gpk_handle h, const gpk_gn_problem* p, Dims& d) {
     return 0;
 }
 
-int g_use_dinv = 1;                  // gpk_debug_set key 10: 0 = substitution strips even when the inverses are supplied
-int g_eikonal_lz = 1;                // gpk_debug_set key 23: 0 = dense schedule for the Eikonal, Burgers and Darcy systems
 
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) { (h)->prof_phase = (i); GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } } while (0)
 
@@ -221,7 +219,7 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
                               double* Hb, int ldh, double alpha, int rev, double** Wout = nullptr, int family = 0) {
     const int nc = d.nz + 1;
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gn: lds/ldh < nz+1");
-    bool dinv = g_use_dinv != 0;
+    bool dinv = h->tune.use_dinv != 0;
     const int db = p->dinv_block > 0 ? p->dinv_block : 256;
     if (db != 256 && db != 512 && db != 1024 && db != 2048) return gpk_bad_arg(h, "gn: dinv_block must be 256, 512, 1024 or 2048");
     for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) dinv = false;
@@ -411,12 +409,9 @@ __global__ __launch_bounds__(1024) void gram_loss_kernel(int nz, const double* _
     }
 }
 
-int g_structured = 1;                // gpk_debug_set key 40: 0 = ignore W1/W2/v0 (always the triangular solve); 1 = honour W1/W2/v0 only
-                                     // (never the Gram blocks); 2 would be redundant: the Gram level is used whenever G/pvec are set
 
 }  // namespace
 
-extern "C" int gpk_debug_set_structured(int v) { g_structured = v; return 0; }
 
 extern "C" int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* p, double* S, int lds, double* W1, double* W2, double* v0, int ldw) {
     if (!h || !S || !W1 || !W2 || !v0) return GPK_ERR_ARG;
@@ -481,18 +476,18 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     // t -- interleaved they form a staircase of slope 1/3 (rev = 3).  Darcy (two factors with different column supports) runs the
     // dense schedule.
     // Darcy (round 4): leading-zero layout with a piecewise profile per factor (darcy_u_profile), only on the GEMM-only solve path
-    const bool darcy_lz = p->system == GPK_GN_DARCY && g_eikonal_lz && g_use_dinv && p->Dinv && p->Dinv2 && p->dinv_block > 0;
+    const bool darcy_lz = p->system == GPK_GN_DARCY && h->tune.eikonal_lz && h->tune.use_dinv && p->Dinv && p->Dinv2 && p->dinv_block > 0;
     const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1
-                  : (p->system == GPK_GN_EIKONAL && g_eikonal_lz) ? 2 : (p->system == GPK_GN_BURGERS && g_eikonal_lz) ? 3 : darcy_lz ? 4 : 0;
+                  : (p->system == GPK_GN_EIKONAL && h->tune.eikonal_lz) ? 2 : (p->system == GPK_GN_BURGERS && h->tune.eikonal_lz) ? 3 : darcy_lz ? 4 : 0;
     struct StairGuard { gpk_handle h; ~StairGuard() { h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0; } } stair_guard{h};
     struct SlopeGuard {                                              // the staircase slope is a property of this step's right-hand sides
         gpk_handle h; explicit SlopeGuard(gpk_handle hh, int s) : h(hh) { h->lead_div = s; } ~SlopeGuard() { h->lead_div = 1; }
     } slope_guard(h, rev == 3 ? 3 : 1);
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
-    const bool gram = g_structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
+    const bool gram = h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
     double* d_loss = h->d_scalars;
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
-    if ((gram || (g_structured && p->W1)) && (long)d.rows * lds < 5L * nz + d.rows)
+    if ((gram || (h->tune.structured && p->W1)) && (long)d.rows * lds < 5L * nz + d.rows)
         return gpk_bad_arg(h, "gn: S too small for the scratch vectors of the structured modes");
     if (gram) {
         // optional Gram level (gpk_gn_gram_prepare): the bordered matrix assembled in O(nz^2), no solve and no product this step
@@ -509,7 +504,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         GPK_TRY(gpk_i_dot(h, coef + 5 * nz, coef + 5 * nz, d.rows, d_loss));
         h->pipe_tev_used = 0; h->prof_pipelined = 0;
         GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));
-    } else if (g_structured && p->system == GPK_GN_ELLIPTIC && p->W1 && p->W2 && p->v0 && p->ldw >= nz + 1) {
+    } else if (h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->W1 && p->W2 && p->v0 && p->ldw >= nz + 1) {
         // optional structured solve (gpk_gn_structured_prepare): one memory-bound pass over W1, W2 instead of the triangular solve
         GPK_PROF_MARK(h, 0);
         double* coef = S;                                            // 3 nz doubles of scratch (S is free in this mode)
@@ -676,5 +671,3 @@ int gpk_i_gn_finish(gpk_handle h, const gpk_gn_problem* p, int nz, int rev, cons
     return 0;
 }
 
-extern "C" int gpk_debug_set_use_dinv(int v) { g_use_dinv = v; return 0; }
-extern "C" int gpk_debug_set_eikonal_lz(int v) { g_eikonal_lz = v; return 0; }

@@ -1,9 +1,11 @@
-"""Loader and prototypes for libgpk.so.  Every symbol declared in include/gpk.h is bound here."""
+"""Loader and prototypes for libgpk.so (the product: include/gpk.h, gpk_mg.h, gpk_debug.h) and libgpk_dev.so (the development build:
+the same plus include/gpk_dev.h -- superseded kernel variants, probes, micro-benchmarks; loaded only on request, by tests and tools)."""
 import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libgpk.so')
+_DEV_LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'libgpk_dev.so')
 
 
 class GpkError(RuntimeError):
@@ -95,7 +97,11 @@ PROTOTYPES = {
     'gpk_gn_loss': (_i, [_vp, _pp, _vp, _vp, _pd]),
     'gpk_gn_hessian_grad': (_i, [_vp, _pp, _vp, _vp, _i, _vp, _i, _vp]),
     'gpk_gn_measurement': (_i, [_vp, _pp, _vp, _vp]),
-    'gpk_debug_set': (_i, [_i, _i]),
+    'gpk_tune': (_i, [_vp, _i, _i]),
+}
+
+# entry points that exist only in the development build libgpk_dev.so (include/gpk_dev.h)
+DEV_PROTOTYPES = {
     'gpk_debug_stamps': (_i, [_vp, C.POINTER(C.c_ulonglong), _i]),
     'gpk_ubench_mfma_f64': (_i, [_vp, _i, _pd]),
     'gpk_ubench_hbm_write': (_i, [_vp, _sz, _i, _pd]),
@@ -107,35 +113,62 @@ PROTOTYPES = {
 }
 
 _lib = None
+_dev_lib = None
 
 
-def library_path():
-    return _LIB_PATH
+def library_path(dev=False):
+    return _DEV_LIB_PATH if dev else _LIB_PATH
 
 
-def declared_symbols():
-    return sorted(PROTOTYPES)
+def declared_symbols(dev=False):
+    return sorted(set(PROTOTYPES) | set(DEV_PROTOTYPES)) if dev else sorted(PROTOTYPES)
 
 
-def load_library():
-    """dlopen libgpk.so and attach prototypes.  Raises GpkError when the library has not been built."""
-    global _lib
-    if _lib is not None:
+def load_library(dev=False):
+    """dlopen libgpk.so (dev=True: libgpk_dev.so) and attach prototypes.  Raises GpkError when the library has not been built."""
+    global _lib, _dev_lib
+    if dev and _dev_lib is not None:
+        return _dev_lib
+    if not dev and _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
-        raise GpkError(f'{_LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+    path = library_path(dev)
+    if not os.path.exists(path):
+        raise GpkError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                        '(hipcc --offload-arch=gfx950); there is no CPU fallback')
     try:
-        lib = C.CDLL(_LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:
-        raise GpkError(f'cannot load {_LIB_PATH}: {e}') from e
-    for name, (res, args) in PROTOTYPES.items():
+        raise GpkError(f'cannot load {path}: {e}') from e
+    protos = dict(PROTOTYPES, **DEV_PROTOTYPES) if dev else PROTOTYPES
+    for name, (res, args) in protos.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    # development aid: GPK_DEBUG_SET="6=0,0=1" applies gpk_debug_set(key, value) pairs at load time (A/B runs of bench.py)
+    # development aid: GPK_DEBUG_SET="6=0,0=1" -> gpk_tune(handle, key, value) on every Context created in this process (A/B runs of
+    # bench.py).  The LIBRARY has no process-wide switches since round 4 (gpk_tune is per handle); what is process-wide here is this
+    # Python-side table of defaults, and `lib.gpk_debug_set(key, value)` -- the call the tests and tools have always used -- is a Python
+    # function attached to the loaded library object that records the pair and applies it to every live Context.
     for kv in filter(None, os.environ.get('GPK_DEBUG_SET', '').split(',')):
         k, v = kv.split('=')
-        lib.gpk_debug_set(int(k), int(v))
-    _lib = lib
+        TUNE_DEFAULTS[int(k)] = int(v)
+    lib.gpk_debug_set = debug_set
+    if dev:
+        _dev_lib = lib
+    else:
+        _lib = lib
     return lib
+
+
+TUNE_DEFAULTS = {}                      # key -> value applied to every new Context (GPK_DEBUG_SET, debug_set)
+LIVE_CONTEXTS = __import__('weakref').WeakSet()
+
+
+def debug_set(key, value):
+    """gpk_tune(handle, key, value) on every live Context, and on every Context created later in this process.  Returns 0, or the
+    library's error code if a handle rejects the key."""
+    TUNE_DEFAULTS[int(key)] = int(value)
+    rc = 0
+    for ctx in list(LIVE_CONTEXTS):
+        if getattr(ctx, 'h', None):
+            rc = ctx.lib.gpk_tune(ctx.h, int(key), int(value)) or rc
+    return rc

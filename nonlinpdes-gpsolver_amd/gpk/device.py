@@ -5,6 +5,7 @@ import weakref
 
 import numpy as np
 
+from . import _lib as _libmod
 from ._lib import GNProblemStruct, GpkError, load_library
 
 LAYOUT = {'Nonlinear_elliptic': 0, 'Burgers': 1, 'Eikonal': 2, 'Darcy_u': 2, 'Darcy_a': 3}
@@ -184,8 +185,11 @@ class GNProblem:
 class Context:
     """One handle = one device + one stream.  Raises GpkError if the library or the device is missing."""
 
-    def __init__(self, device=0):
-        self.lib = load_library()
+    def __init__(self, device=0, dev=False):
+        """dev=True: the handle lives in libgpk_dev.so, the development build with the superseded kernel variants, probes and
+        micro-benchmarks (include/gpk_dev.h) -- tests and tools only"""
+        self.dev = bool(dev)
+        self.lib = load_library(dev=self.dev)
         h = C.c_void_p()
         rc = self.lib.gpk_create(int(device), C.byref(h))
         if rc != 0:
@@ -193,6 +197,18 @@ class Context:
                            '(this library has no CPU fallback)')
         self.h = h
         self._live = weakref.WeakSet()          # device arrays allocated through this context and not yet freed
+        self.tune_rejected = {}
+        for k, v in _libmod.TUNE_DEFAULTS.items():        # development switches in force for this process (GPK_DEBUG_SET / gpk.debug_set)
+            if self.lib.gpk_tune(self.h, int(k), int(v)) != 0:
+                # (a value that selects a superseded design while this handle lives in the product library, which does not contain it)
+                self.tune_rejected[int(k)] = int(v)
+                import warnings
+                warnings.warn(f'gpk: tuning key {k} = {v} is not available in {"libgpk_dev.so" if self.dev else "libgpk.so"}; this handle keeps its default')
+        _libmod.LIVE_CONTEXTS.add(self)
+
+    def tune(self, key, value):
+        """per-handle development / tuning switch (gpk_tune; keys: GpkTune in csrc/gpk_common.h, tools/README.md)"""
+        self._chk(self.lib.gpk_tune(self.h, int(key), int(value)))
 
     def _chk(self, rc):
         if rc < 0:
@@ -393,7 +409,7 @@ class Context:
         self._chk(self.lib.gpk_prof_read_assembly(self.h, C.byref(ms)))
         return ms.value
 
-    # ---- micro-benchmarks ----
+    # ---- micro-benchmarks (development build only: Context(dev=True)) ----
     def ubench_mfma_f64(self, iters=20000):
         v = C.c_double()
         self._chk(self.lib.gpk_ubench_mfma_f64(self.h, iters, C.byref(v)))

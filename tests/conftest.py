@@ -29,3 +29,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope='module')
+def dev_ctx():
+    """A handle in libgpk_dev.so -- the development build that also holds the superseded kernel variants (gpk_tune keys 5, 7, 21, 4 = 2),
+    the probes and the micro-benchmarks (include/gpk_dev.h).  The product library libgpk.so rejects those keys."""
+    import gpk
+    c = gpk.Context(0, dev=True)
+    yield c
+    c.close()

@@ -236,10 +236,11 @@ def test_potrf(ctx, n):
 
 
 @pytest.mark.parametrize('panel', [1, 2, 3])
-def test_potrf_grid_larger_than_resident(ctx, panel):
-    """Panel kernels with more workgroups than the chip holds at once (the third design keeps one workgroup per CU: 261 > 256): the
+def test_potrf_grid_larger_than_resident(dev_ctx, panel):
+    """(development build: the third design lives in csrc/dev/)  Panel kernels with more workgroups than the chip holds at once (the third design keeps one workgroup per CU: 261 > 256): the
     workgroup that stores the diagonal block waits for the others' load tickets, so it must be one that is dispatched AFTER them (a
     wait for a later workgroup starves when that workgroup is bound to the waiting one's CU).  Checked through sampled entries of L L^T."""
+    ctx = dev_ctx
     n, k = 16640, 48
     rng = np.random.RandomState(3)
     M = rng.normal(size=(k, n))
@@ -327,7 +328,8 @@ def test_trsm_dinv(ctx, n, nrhs, lead, block):
 
 @pytest.mark.parametrize('mode', [1, 2, 0])                       # data-tagged hand-offs (default), flags, two launches per block
 @pytest.mark.parametrize('n', [1, 64, 100, 1000, 3001])
-def test_trsv_and_potrs(ctx, n, mode):
+def test_trsv_and_potrs(dev_ctx, n, mode):
+    ctx = dev_ctx                                                 # (the flag-chained form, mode 2, exists only in the development build)
     rng = np.random.RandomState(n)
     A = _spd(rng, n)
     b = rng.normal(size=n)
@@ -488,7 +490,8 @@ def test_notebook_kat_on_device(ctx):
     assert np.sqrt(np.sum(err ** 2) / 900) == pytest.approx(R.ELLIPTIC_PTS_L2, rel=1e-7)
 
 
-def test_microbenchmarks_run(ctx):
+def test_microbenchmarks_run(dev_ctx):
+    ctx = dev_ctx
     tf = ctx.ubench_mfma_f64(5000)
     bw = ctx.ubench_hbm_write(1 << 28, 5)
     print(f'\n[ubench] v_mfma_f64_16x16x4_f64: {tf:.1f} TFLOP/s   streaming fp64 stores: {bw:.0f} GB/s')

@@ -134,9 +134,10 @@ def test_cholesky_and_gn_step_with_tile_lists_everywhere(ctx):
     assert np.linalg.norm(sols[0] - sols[2]) <= 1e-9 * np.linalg.norm(sols[2])
 
 
-def test_lds_dma_feed_probe_kernel(ctx):
-    """the LDS-DMA experiment kernel (gpk_debug_gemm_dma, csrc/gpk_gemm_dma_probe.hip; not on the product path): same bits as the
+def test_lds_dma_feed_probe_kernel(dev_ctx):
+    """the LDS-DMA experiment kernel (gpk_debug_gemm_dma, csrc/dev/gpk_gemm_dma_probe.hip; development build only): same bits as the
     product kernel -- same tile, same summation order -- on shapes with several K slabs and tiles"""
+    ctx = dev_ctx
     rng = np.random.RandomState(3)
     for m, n, k in ((64, 64, 16), (192, 256, 208), (640, 128, 1024)):
         A = rng.normal(size=(m, k)); B = rng.normal(size=(k, n))

@@ -68,8 +68,9 @@ def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
 
 
 def test_schedule_variants_agree():
+    # (development build: the list includes the superseded designs of csrc/dev/gpk_factor_retired.inc)
     import gpk
-    ctx = gpk.Context(0)
+    ctx = gpk.Context(0, dev=True)
     np.random.seed(5)
     from src.sample_points import sampled_pts_rdm
     Nd, Nb = 1100, 160                                           # N = 2360 (10 strips), n_z = 1100 (18 panels / TRSV blocks, 3 pipeline blocks)
@@ -88,7 +89,7 @@ def test_schedule_variants_agree():
 
 def test_latency_probes_run():
     import gpk
-    ctx = gpk.Context(0)
+    ctx = gpk.Context(0, dev=True)
     vals = [ctx.ubench_latency(m) for m in range(7)]
     print('\n[ubench] cycles/op: dep fma64 %.1f, indep fma64 %.1f, dep ds_read %.1f, indep ds_read %.1f, dep mfma %.1f, '
           'dep global (1 line) %.1f, dep global (16 lines) %.1f' % tuple(vals))

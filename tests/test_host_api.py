@@ -125,21 +125,34 @@ def test_driver_flags_match_reference_defaults():
 
 
 # ---- the C-ABI library ---------------------------------------------------------------------------------------------
-def test_library_exports_every_declared_symbol():
-    import gpk
+def _declared(headers):
     declared = set()
-    for name in ('gpk.h', 'gpk_mg.h', 'gpk_debug.h'):            # the boundary, its multi-GPU part, the development aids
+    for name in headers:
         hdr = open(os.path.join(ROOT, 'include', name)).read()
         hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)          # (prose in comments mentions calls like gpk_mg_rccl_init())
         declared |= set(re.findall(r'\b(gpk_[a-z0-9_]+)\s*\(', hdr))
-    declared -= {'gpk_ctx'}
-    assert declared, 'no declarations parsed'
-    if not os.path.exists(gpk.library_path()):
-        pytest.skip('libgpk.so not built (run __graft_entry__.build())')
+    return declared - {'gpk_ctx'}
+
+
+def test_library_exports_every_declared_symbol():
+    """libgpk.so (the product) exports exactly the boundary -- gpk.h, gpk_mg.h -- plus the one per-handle tuning call of gpk_debug.h;
+    libgpk_dev.so (tests / tools only) exports those and the development entry points of gpk_dev.h.  The product must NOT carry
+    probes, micro-benchmarks or process-wide switches (round 4)."""
+    import gpk
+    product = _declared(('gpk.h', 'gpk_mg.h', 'gpk_debug.h'))
+    dev_only = _declared(('gpk_dev.h',)) - product
+    assert product and dev_only, 'no declarations parsed'
+    for dev, declared in ((False, product), (True, product | dev_only)):
+        path = gpk.library_path(dev=dev)
+        if not os.path.exists(path):
+            pytest.skip(f'{os.path.basename(path)} not built (run __graft_entry__.build())')
+        lib = ctypes.CDLL(path)
+        missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+        assert not missing, (path, missing)
+        assert declared == set(gpk.declared_symbols(dev=dev)), declared ^ set(gpk.declared_symbols(dev=dev))
     lib = ctypes.CDLL(gpk.library_path())
-    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
-    assert not missing, missing
-    assert declared == set(gpk.declared_symbols()), declared ^ set(gpk.declared_symbols())
+    leaked = [s for s in sorted(dev_only) + ['gpk_debug_set'] if hasattr(lib, s)]
+    assert not leaked, f'development entry points in the product library: {leaked}'
 
 
 def test_gn_problem_struct_matches_header():

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Two ranks of bench.py on ONE GPU (process group over gloo instead of RCCL, which refuses two ranks on one device): exercises
-# the N > 1 control flow of the benchmark with the real kernels -- replicas of config 2, then the sharded config 5 with BOTH
+# the N > 1 control flow of the benchmark with the real kernels -- replicas of config 2 (secondary), then the sharded config 5 (= `value`
+# since round 4, with the same configuration on rank 0 alone beside it) with BOTH
 # executors of the plan: the native one (gpk_mg_*, collectives = host-staged stand-ins bound to the ncclBroadcast /
 # ncclAllGather entry points) and the Python one over torch.distributed.  Run through gpurun from the repo root.
 PORT=29533
@@ -12,7 +13,11 @@ for engine in native python; do
   wait
   echo "== executor: $engine"
   grep "^{" gpurun_out/bench2_${engine}_rank0.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); sc=d.get('sharded_config'); print('value', d['value'], 'n_gpus', d['n_gpus'], d['scaling'], d['ms_per_step'], d['l2_error']['pts_L2_err']); print('sharded', {k: sc.get(k) for k in ('value','n_gpus','ms_per_step','f1_tflops','one_time_ms','error','mode_probe')}, sc.get('l2_error'), sc.get('config', {}).get('executor'))"
+import json,sys; d=json.loads(sys.stdin.read())
+print('value (sharded config 5)', d['value'], 'n_gpus', d['n_gpus'], d['scaling'], 'ms/step', d['ms_per_step'], 'pts_L2_err', d['l2_error']['pts_L2_err'])
+print('vs_1gpu', d.get('vs_1gpu'), 'one GPU in the same job:', (d.get('one_gpu_same_job') or {}).get('ms_per_step'), 'executor:', d['config'].get('executor'))
+print('mode_probe', d.get('mode_probe')); print('parity', {k: (d.get('parity') or {}).get(k) for k in ('z1_rel_dev_vs_B2', 'ok', 'skipped')}, 'parity_failed', d.get('parity_failed'))
+print('replicas_c2', {k: (d.get('replicas_c2') or {}).get(k) for k in ('value', 'n_gpus', 'scaling', 'ms_per_step', 'error')})"
   tail -2 gpurun_out/bench2_${engine}_rank1.log
   PORT=$((PORT+1))
 done

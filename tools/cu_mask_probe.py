@@ -2,7 +2,7 @@
 """Which CUs does a CU-masked stream use?  (bit i of the mask -> which XCD / CU)  Development probe."""
 import sys; sys.path.insert(0, "nonlinpdes-gpsolver_amd")
 import ctypes as C, numpy as np, gpk
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 n = 4096
 for first, nbits in ((0, 8), (0, 32), (0, 64), (32, 32), (64, 192), (0, 256), (8, 8), (0, 1), (1, 1), (8, 1)):
     out = (C.c_int * n)()

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
 import gpk
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 lib = ctx.lib
 def timed(fn, reps=5):
     fn(); fn(); ctx.synchronize(); best = 1e30

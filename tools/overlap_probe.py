@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
 import gpk
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 lib = C.CDLL(os.path.join(ROOT, 'nonlinpdes-gpsolver_amd', 'csrc', 'libgpk.so'))
 rng = np.random.RandomState(0)
 n, k = 4001, 8400

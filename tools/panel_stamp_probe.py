@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
 import gpk
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 buf = (C.c_ulonglong * 16)()
 ctx.lib.gpk_debug_stamps(ctx.h, None, 1)
 rng = np.random.RandomState(0)

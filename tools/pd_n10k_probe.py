@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
 import gpk
 from src.sample_points import sampled_pts_rdm
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 np.random.seed(0)
 Xd, Xb = sampled_pts_rdm(10000, 1000, [[0, 1], [0, 1]], time_dependent=False)
 for nug in (1e-13, 1e-6):

@@ -28,7 +28,7 @@ def main():
     ap.add_argument('--nugget', type=float, default=1e-13)
     ap.add_argument('--steps', type=int, default=3)
     a = ap.parse_args()
-    ctx = gpk.Context(0)
+    ctx = gpk.Context(0, dev=True)
     print(json.dumps(ctx.device_info()))
     print('ubench mfma f64 TF/s', ctx.ubench_mfma_f64(20000), ' hbm write GB/s', ctx.ubench_hbm_write(1 << 30, 10))
     Nd, Nb = a.Nd, a.Nb

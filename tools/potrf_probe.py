@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'nonlinpdes-gpsolver_amd'))
 import gpk
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 rng = np.random.RandomState(0)
 for n in (512, 1024, 4001):
     M = rng.normal(size=(n, n)); A = M @ M.T + n * np.eye(n)

@@ -1,6 +1,6 @@
 import sys; sys.path.insert(0, "nonlinpdes-gpsolver_amd")
 import ctypes as C, numpy as np, gpk
-ctx = gpk.Context(0)
+ctx = gpk.Context(0, dev=True)
 for mode in (0, 1):
     n = 4096
     out = (C.c_int * n)()
