@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof/pmc_n10k_busy (tools/profile_round.sh, step 5) -> profiles/<round>_pmc_potrf_n10k.json: MFMA-busy fraction of the
+"""gpurun_out/prof/pmc_n10k_SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE (tools/profile_round.sh, steps 4-5) -> profiles/<round>_pmc_potrf_n10k.json: MFMA-busy fraction of the
 Cholesky factorisation's launches at the north-star size (N_domain = 10000, Theta of order 21000).
 
-Dispatches are taken from the run `bench.py --workload n10k --steps 1`: everything between the first and the last
+Dispatches are taken from the run `bench.py --workload n10k --steps 2 --warmup 1`: everything between the first and the last
 potrf_panel_mfma_kernel dispatch that precedes the first gn_build_kernel belongs to gpk_potrf(Theta) (it runs twice: cold + warm).
   * trailing updates  = gemm_f64_kernel<.., false, true, ..> (NT, lower tiles; one per 512-column block)
   * panel kernels     = potrf_panel_mfma_kernel (fused variant: the previous panel's rank-64 updates ride inside)
@@ -11,7 +11,7 @@ XCDs: busy fraction = busy / 1024 / (GUI_ACTIVE / 8); executed flops = busy / 64
 import csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r03'
-f = glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof', 'pmc_n10k_busy', '**', '*counter_collection.csv'), recursive=True)
+f = glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof', 'pmc_n10k_SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE', '**', '*counter_collection.csv'), recursive=True)
 if not f:
     sys.exit('no counter file')
 rows = {}
