@@ -177,10 +177,22 @@ class _GPEquation(object):
                     print('iter = 0', 'Loss =', value)
                 else:
                     print('iter = ', it, 'Gauss-Newton step size =', step_size, ' Loss = ', value)
-        for it in range(max_iter):
-            loss_in, _info = ctx.gn_step(prob, z, step_size)      # loss of the iterate the step starts from
-            record(it, loss_in)
-        record(max_iter, ctx.gn_loss(prob, z))
+        # The loss history is the reference's: J(z_0), then J(z_k) after every update (src/PDEs.py:108-124).  Every value comes from
+        # gpk_gn_loss -- true substitution with the factor, exact to rounding -- since round 4.  gpk_gn_step also returns the loss of the
+        # iterate it starts from, for free, as the squared norm of the F column of its GEMM-only solve; through the explicit inverses of
+        # the diagonal blocks that number carries ~1e-8 relative error at nugget <= 1e-12 near convergence (DESIGN.md section 4
+        # "Numerics"), which is not what a user comparing digits with the reference expects.  GPK_INSTEP_LOSS=1 takes the free numbers
+        # again (one triangular solve with one vector less per step: 3-5 % of a step at BASELINE config 2).
+        if os.environ.get('GPK_INSTEP_LOSS', '0') == '1':
+            for it in range(max_iter):
+                loss_in, _info = ctx.gn_step(prob, z, step_size)  # loss of the iterate the step starts from
+                record(it, loss_in)
+            record(max_iter, ctx.gn_loss(prob, z))
+        else:
+            record(0, ctx.gn_loss(prob, z))
+            for it in range(1, max_iter + 1):
+                ctx.gn_step(prob, z, step_size)
+                record(it, ctx.gn_loss(prob, z))
         self.max_iter = max_iter
         self.step_size = step_size
         self.loss_hist = loss_hist

@@ -110,3 +110,53 @@ def test_one_context_alternating_problem_shapes():
         np.testing.assert_array_equal(H, Hw)
         np.testing.assert_array_equal(z.download(), zw)
     c.close()
+
+
+def test_round4_entry_points_reject_bad_arguments_and_handle_edges():
+    """gpk_tune (unknown key, development-only variants in the product library), gpk_error_metrics (n = 1, n <= 0, null pointers),
+    gpk_prof_read_assembly before any timed assembly, Darcy in the leading-zero layout without data points and without boundary
+    points."""
+    import ctypes as C
+    import gpk
+    from oracle import gp_oracle as O
+    ctx = gpk.Context(0)
+    assert ctx.lib.gpk_tune(ctx.h, 9999, 1) < 0
+    for key, value in ((5, 0), (7, 1), (21, 0), (21, 2), (4, 2), (11, 32)):     # superseded designs: development build only
+        assert ctx.lib.gpk_tune(ctx.h, key, value) < 0, (key, value)
+        assert 'development build' in ctx.lib.gpk_last_error(ctx.h).decode()
+    assert ctx.lib.gpk_tune(ctx.h, 21, 1) == 0 and ctx.lib.gpk_tune(ctx.h, 4, 0) == 0 and ctx.lib.gpk_tune(ctx.h, 4, 1) == 0
+    dev = gpk.Context(0, dev=True)
+    assert dev.lib.gpk_tune(dev.h, 21, 2) == 0 and dev.lib.gpk_tune(dev.h, 21, 1) == 0      # ... and it has them
+    dev.close()
+    mx, l2 = C.c_double(), C.c_double()
+    one = ctx.array(np.array([3.0])); two = ctx.array(np.array([1.0]))
+    assert ctx.lib.gpk_error_metrics(ctx.h, 1, one.ptr, two.ptr, None, C.byref(mx), C.byref(l2)) == 0
+    assert mx.value == 2.0 and l2.value == 2.0
+    assert ctx.lib.gpk_error_metrics(ctx.h, 0, one.ptr, two.ptr, None, C.byref(mx), C.byref(l2)) < 0
+    assert ctx.lib.gpk_error_metrics(ctx.h, 1, None, two.ptr, None, C.byref(mx), C.byref(l2)) < 0
+    ms = C.c_double()
+    assert ctx.lib.gpk_prof_read_assembly(ctx.h, C.byref(ms)) < 0               # nothing timed yet
+    # Darcy, leading-zero layout (default): N_data = 0 and N_boundary = 0 against the dense schedule
+    rng = np.random.RandomState(8)
+    for Nd, Nb, Ndata in ((150, 40, 0), (130, 0, 10)):
+        Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+        Tu, _ = ctx.assemble('Darcy_u', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+        Ta, _ = ctx.assemble('Darcy_a', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+        assert ctx.potrf(Tu) == 0 and ctx.potrf(Ta) == 0
+        data = 0.1 * rng.normal(size=Ndata) if Ndata else np.zeros(0)
+        z0 = 0.2 * rng.normal(size=6 * Nd)
+        outs = []
+        for mode in (1, 0):
+            ctx.lib.gpk_debug_set(23, mode)
+            try:
+                prob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, np.ones(Nd), np.zeros(Nb), Tu, p0=1e-2, data_u=data if Ndata else None, L2=Ta)
+                z = ctx.array(z0)
+                loss, info = ctx.gn_step(prob, z)
+                assert info == 0 and np.isfinite(loss)
+                outs.append((z.download().copy(), loss))
+                prob.release_workspace()
+            finally:
+                ctx.lib.gpk_debug_set(23, 1)
+        assert np.linalg.norm(outs[0][0] - outs[1][0]) <= 1e-9 * np.linalg.norm(outs[1][0])
+        assert outs[0][1] == pytest.approx(outs[1][1], rel=1e-10)
+    ctx.close()

@@ -199,3 +199,33 @@ def test_error_metrics_on_device_match_the_reference_definitions():
     _, mx, l2 = ctx.error_metrics(t, a)
     assert np.isnan(mx) and np.isnan(l2)
     ctx.close()
+
+
+def test_class_api_loss_history_is_exact(monkeypatch):
+    """Round 4: the loss history of GN_method comes from gpk_gn_loss (true substitution) for every entry -- at nugget 1e-12 the free
+    in-step value of gpk_gn_step (explicit diagonal-block inverses) is only good to ~1e-8 near convergence.  Checked against the oracle's
+    loss of the final iterate on the device's own factor; GPK_INSTEP_LOSS=1 restores the cheaper history, same iterates."""
+    from oracle import gp_oracle as O
+    from src.PDEs import Nonlinear_elliptic2d
+
+    def run():
+        np.random.seed(4)
+        e = Nonlinear_elliptic2d(alpha=1.0, m=3, bdy=lambda x1, x2: O.elliptic_truth(x1, x2), rhs=lambda x1, x2: O.elliptic_rhs(x1, x2))
+        e.sampled_pts(1200, 160)
+        e.Gram_matrix(kernel='Gaussian', kernel_parameter=0.2, nugget=1e-12, nugget_type='adaptive')
+        e.Gram_Cholesky()
+        e.GN_method(max_iter=6, step_size=1, initial_sol='rdm', print_hist=False)
+        return e
+
+    e = run()
+    assert len(e.loss_hist) == 7 and e.chol_info == 0
+    sysm = O.EllipticSystem(1.0, 3.0, e.rhs_f, e.bdy_g)
+    want_last = O.loss(sysm, [e.L], e.sol_sampled_pts)
+    want_first = O.loss(sysm, [e.L], e.init_sol)
+    assert e.loss_hist[-1] == pytest.approx(want_last, rel=1e-9)
+    assert e.loss_hist[0] == pytest.approx(want_first, rel=1e-12)
+    monkeypatch.setenv('GPK_INSTEP_LOSS', '1')
+    f = run()
+    np.testing.assert_array_equal(f.sol_sampled_pts, e.sol_sampled_pts)       # same steps, only the reported numbers differ
+    np.testing.assert_allclose(f.loss_hist, e.loss_hist, rtol=1e-5)
+    assert f.loss_hist[-1] == e.loss_hist[-1]                                # the closing value always came from gpk_gn_loss
