@@ -15,7 +15,7 @@ f = glob.glob(os.path.join(ROOT, 'gpurun_out', 'prof', 'pmc_n10k_SQ_VALU_MFMA_BU
 if not f:
     sys.exit('no counter file')
 rows = {}
-for r in csv.DictReader(open(f[0])):
+for r in csv.DictReader(open(max(f, key=os.path.getmtime))):      # the newest pass (earlier rounds' files may sit beside it)
     k = int(r['Dispatch_Id'])
     d = rows.setdefault(k, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']), 'dur_us': (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3})
     d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])

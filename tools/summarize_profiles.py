@@ -12,8 +12,11 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
 DST = os.path.join(ROOT, 'profiles')
 
 def one(pattern):
+    """the NEWEST match: gpurun merges every call's files into the same local tree, and rocprofv3 names its outputs by process id, so
+    files of earlier profile rounds can sit next to the current ones (that is how a round-3 table named a kernel the round-3 build no
+    longer launched); tools/profile_round.sh is best run after `rm -rf gpurun_out/prof` here"""
     g = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None
 
 def counters(name):
     f = one(f'pmc_{name}/**/*counter_collection.csv')
