@@ -1002,7 +1002,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
         }
         # CPU oracle on the device's factor (B2 only: the reference operation sequence needs minutes at order 34000), `parity` beside it
         need_gb = 3.2 * 8.0 * N * N / 1e9 + 4.0 * 8.0 * N * (nz + 1) / 1e9
-        if not args.no_cpu_baseline and not args.no_sharded_parity:
+        if not args.no_cpu_baseline and not args.no_sharded_parity and not solo:   # (solo = the 1-GPU point inside an N-rank job: the N-rank run carries the parity)
             if host_mem_available_gb() > need_gb + 16:
                 from oracle import gp_oracle as O
                 Lh = np.ascontiguousarray(tril_inplace(Theta.cpu().numpy()[:, :N]))

@@ -464,6 +464,23 @@ extern "C" int gpk_gn_dims(const gpk_gn_problem* p, int* nz, int* s_rows) {
     return 0;
 }
 
+extern "C" int gpk_gn_worksize(const gpk_gn_problem* p, int lds, int* host_lds, size_t* S_bytes, size_t* Hb_bytes, size_t* delta_bytes,
+                               size_t* handle_bytes) {
+    Dims d;
+    if (!p || gn_dims(p, d) != 0) return GPK_ERR_ARG;
+    const int nc = d.nz + 1;
+    if (lds == 0) lds = ((nc + 15) / 16) * 16;
+    if (lds < nc) return GPK_ERR_ARG;
+    bool dinv = p->dinv_block > 0;
+    for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) dinv = false;
+    if (host_lds) *host_lds = lds;
+    if (S_bytes) *S_bytes = (size_t)d.rows * lds * sizeof(double);
+    if (Hb_bytes) *Hb_bytes = (size_t)nc * lds * sizeof(double);
+    if (delta_bytes) *delta_bytes = (size_t)d.nz * sizeof(double);
+    if (handle_bytes) *handle_bytes = dinv ? (size_t)d.rows * lds * sizeof(double) : 0;
+    return 0;
+}
+
 extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, double step_size, double* S, int lds,
                            double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info) {
     if (!h || !z || !S || !Hb || !delta) return GPK_ERR_ARG;

@@ -88,6 +88,7 @@ PROTOTYPES = {
     'gpk_gemm': (_i, [_vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _i, _d, _vp, _i]),
     'gpk_syrk': (_i, [_vp, _i, _i, _d, _vp, _i, _d, _vp, _i, _i]),
     'gpk_gn_dims': (_i, [_pp, _pi, _pi]),
+    'gpk_gn_worksize': (_i, [_pp, _i, _pi, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     'gpk_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _i, _vp, _pd, _pi]),
     'gpk_gn_structured_prepare': (_i, [_vp, _pp, _vp, _i, _vp, _vp, _vp, _i]),
     'gpk_gn_gram_prepare': (_i, [_vp, _pp, _vp, _i, _vp]),

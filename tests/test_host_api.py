@@ -197,3 +197,31 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, os.path.join(dirpath, f)
+
+
+def test_gn_worksize_query_runs_without_a_device():
+    """gpk_gn_dims / gpk_gn_worksize are pure host functions (SURVEY 8b B3 "workspace queries"): sizes of the caller-owned arrays of
+    the Gauss-Newton step for every system, the admissible leading dimension, the handle's own reservation."""
+    import ctypes as C
+    import gpk
+    from gpk._lib import GNProblemStruct
+    if not os.path.exists(gpk.library_path()):
+        pytest.skip('libgpk.so not built')
+    lib = gpk.load_library()
+    cases = {0: (lambda Nd, Nb, Nk: (Nd, 2 * Nd + Nb)), 1: (lambda Nd, Nb, Nk: (3 * Nd, 4 * Nd + Nb)), 2: (lambda Nd, Nb, Nk: (3 * Nd, 4 * Nd + Nb)),
+             3: (lambda Nd, Nb, Nk: (6 * Nd, 7 * Nd + Nb + Nk)), 4: (lambda Nd, Nb, Nk: (2 * Nd, 3 * Nd + Nb))}
+    for system, dims in cases.items():
+        for Nd, Nb, Nk in ((900, 124, 40), (37, 0, 5)):
+            ps = GNProblemStruct()
+            ps.system, ps.Nd, ps.Nb, ps.Ndata = system, Nd, Nb, Nk if system == 3 else 0
+            nz, rows = C.c_int(), C.c_int()
+            assert lib.gpk_gn_dims(C.byref(ps), C.byref(nz), C.byref(rows)) == 0
+            assert (nz.value, rows.value) == dims(Nd, Nb, Nk)
+            ld = C.c_int(); sb, hb, db, wb = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+            assert lib.gpk_gn_worksize(C.byref(ps), 0, C.byref(ld), C.byref(sb), C.byref(hb), C.byref(db), C.byref(wb)) == 0
+            assert ld.value % 16 == 0 and nz.value + 1 <= ld.value < nz.value + 17
+            assert sb.value == rows.value * ld.value * 8 and hb.value == (nz.value + 1) * ld.value * 8 and db.value == nz.value * 8
+            assert wb.value == 0                                  # no inverted diagonal blocks supplied: nothing reserved by the handle
+            assert lib.gpk_gn_worksize(C.byref(ps), nz.value, None, None, None, None, None) < 0      # lds < nz + 1
+    ps = GNProblemStruct(); ps.system = 99; ps.Nd = 10
+    assert lib.gpk_gn_worksize(C.byref(ps), 0, None, None, None, None, None) < 0
