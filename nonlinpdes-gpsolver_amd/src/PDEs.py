@@ -6,7 +6,6 @@ Differences that are deliberate: no stale jit cache when Gram_ma
 may be numpy-vectorised or plain scalar Python functions.
 """
 import os
-import sys
 
 import numpy as onp
 from numpy import random
