@@ -103,7 +103,7 @@ struct GpkTune {
     int sk_snap = 4;                    // key 44: a share boundary closer than this many slabs to a tile boundary moves there
     int force_cfg = 0;                  // key 0: development aid (): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
     int use_dinv = 1;                   // key 10: 0 = substitution strips even when the inverses are supplied
-    int eikonal_lz = 1;                 // key 23: 0 = dense schedule for the Eikonal, Burgers and Darcy systems
+    int eikonal_lz = 1;                 // key 23: 0 = dense schedule for the Eikonal, Burgers and Darcy systems; 2 = leading-zero layout with the conservative closed-form staircase for Eikonal (round 2-3) instead of the exact two-segment profile
     int structured = 1;                 // key 40: 0 = ignore W1/W2/v0 (always the triangular solve); 1 = honour W1/W2/v0 only (never the Gram blocks); 2 would be redundant: the Gram level is used whenever G/pvec are set
 };
 

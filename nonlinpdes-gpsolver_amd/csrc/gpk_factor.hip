@@ -1466,6 +1466,7 @@ int gpk_i_syrk_potrf(gpk_handle h, const double* W, int ldw, int rows, int nc, i
         }
         const int ph = h->prof_phase;
         h->prof_phase = 2;                                           // (flop accounting: the product, apart from the factorisation's updates)
+        h->stair_col0 = 0; h->stair_row0 = 0;                        // (a piecewise profile set by the caller, gpk_ctx::stair, is in W's own frame)
         const int rcp = gpk_i_gemm(h, true, false, nc, nc, rows, 1.0, W, ldw, W, ldw, 0.0, Hb, ldh, true, lead);
         h->prof_phase = ph;
         GPK_TRY(rcp);
@@ -1496,6 +1497,7 @@ static int potrf_pipelined(gpk_handle h, const double* W, int ldw, int rows, int
         const long tiles = (long)gpk_ceil_div(nc - j0, th) * gpk_ceil_div(j1 - j0, 64);
         h->splitk_req = h->tune.pipeline_units > 0 ? (int)((h->tune.pipeline_units + tiles / 2) / tiles) : 0;
         h->tile_req = jb > 0 ? h->tune.pipeline_tile : 0;
+        h->stair_col0 = j0; h->stair_row0 = 0;                       // (piecewise profile of the caller: this product's column 0 is W's column j0)
         const int r = gpk_i_gemm(h, true, false, nc - j0, j1 - j0, rows, 1.0, W + j0, ldw, W + j0, ldw, 0.0, Hb + (long)j0 * ldh + j0, ldh, false,
                                  lead > j0 ? lead - j0 : 0, false, true);
         h->splitk_req = 0; h->tile_req = 0;

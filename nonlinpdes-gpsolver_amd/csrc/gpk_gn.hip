@@ -79,6 +79,18 @@ __host__ __device__ __forceinline__ int stair_pos(int rev, int Nd, int j) {
 // the w2, w1 columns, slope 1 again over v2, v1 (row 6 N_d - 1 - c) -- three segments of a GpkStair -- and for the a-part ONE slope-1
 // staircase over the contiguous columns [N_d, 4 N_d) (row 4 N_d - 1 - c: the closed form with lead = 3 N_d on that sub-range), all
 // other columns zero.  Executed flops of the solve: 27 % of the dense count; of the product: 38 %.
+// Eikonal system (round 4): unknown groups in the order v1, v2, v0, i.e. columns [v0 | v2 v1] in memory.  First non-zero rows of A(z)
+// (src/PDEs.py:441-449 of the reference): v1_t: t, v2_t: N_d + t, v0_t: 3 N_d + t -- slope 1 over the v2, v1 columns (row 3 N_d - 1 - c)
+// and slope 1 again, N_d rows LATER, over the v0 columns (row 4 N_d - 1 - c).  Until round 3 the closed form treated the v0 columns as if
+// they started at row 2 N_d + t (conservative: N_d rows of zeros were multiplied through); the two-segment profile is exact.
+inline GpkStair eikonal_profile(int Nd) {
+    GpkStair st;
+    st.nseg = 2;
+    st.c1[0] = Nd;     st.a[0] = 0; st.b[0] = 4 * Nd - 1; st.sd[0] = 1;
+    st.c1[1] = 3 * Nd; st.a[1] = 0; st.b[1] = 3 * Nd - 1; st.sd[1] = 1;
+    return st;
+}
+
 inline GpkStair darcy_u_profile(int Nd) {
     GpkStair st;
     st.nseg = 3;
@@ -497,6 +509,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1
                   : (p->system == GPK_GN_EIKONAL && h->tune.eikonal_lz) ? 2 : (p->system == GPK_GN_BURGERS && h->tune.eikonal_lz) ? 3 : darcy_lz ? 4 : 0;
     struct StairGuard { gpk_handle h; ~StairGuard() { h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0; } } stair_guard{h};
+    // Eikonal on the GEMM-only solve path: the exact two-segment profile for the solve and for the products (pipelined or not); the
+    // substitution path (gpk_tune(10, 0)) keeps the conservative closed form, which gpk_i_trsm_left_lz understands
+    if (rev == 2 && h->tune.use_dinv && p->Dinv && p->dinv_block > 0 && h->tune.eikonal_lz != 2) h->stair = eikonal_profile(p->Nd);
     struct SlopeGuard {                                              // the staircase slope is a property of this step's right-hand sides
         gpk_handle h; explicit SlopeGuard(gpk_handle hh, int s) : h(hh) { h->lead_div = s; } ~SlopeGuard() { h->lead_div = 1; }
     } slope_guard(h, rev == 3 ? 3 : 1);

@@ -113,7 +113,7 @@ def test_eikonal_leading_zero_layout_agrees_with_dense_schedule():
     z0 = np.zeros(3 * Nd)
     out = {}
     try:
-        for mode in (1, 0):
+        for mode in (1, 2, 0):                                    # exact two-segment profile (default), conservative closed form, dense
             ctx.lib.gpk_debug_set(23, mode)
             prob = gpk.GNProblem(ctx, 'Eikonal', Nd, Nb, f, g, T, p0=eps)
             z = ctx.array(z0)
@@ -126,8 +126,9 @@ def test_eikonal_leading_zero_layout_agrees_with_dense_schedule():
             out[mode] = (z.download().copy(), np.array(hist))
     finally:
         ctx.lib.gpk_debug_set(23, 1)
-    assert np.max(np.abs(out[1][0] - out[0][0])) <= 1e-9 * np.max(np.abs(out[0][0]))
-    np.testing.assert_allclose(out[1][1], out[0][1], rtol=1e-8)
+    for m in (1, 2):
+        assert np.max(np.abs(out[m][0] - out[0][0])) <= 1e-9 * np.max(np.abs(out[0][0])), m
+        np.testing.assert_allclose(out[m][1], out[0][1], rtol=1e-8)
     sol_ref, hist_ref = O.gn_method(O.EikonalSystem(eps, f, g), [L], z0, 4, 1)
     assert np.linalg.norm(out[1][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
     np.testing.assert_allclose(out[1][1], hist_ref, rtol=1e-6)
