@@ -1073,6 +1073,10 @@ def main():
             if rep is not None:
                 rep['fallback'] = ('the sharded BASELINE config 5 run did not complete (see sharded_config.error): `value` is the aggregate of N '
                                    'independent config-2 replicas, NOT the strong-scaling figure')
+        if rep is None and rank == 0:                             # (--no-replicas: still leave ONE line behind if the sharded run dies)
+            rep = {'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points', 'value': None, 'unit': 'GN steps/s',
+                   'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'strong',
+                   'fallback': 'the sharded BASELINE config 5 run did not complete (see sharded_config.error) and the replicas were skipped'}
         watch = AbortWatch(rank, rep, use_store=True)
         solo = None
         try:
@@ -1096,7 +1100,7 @@ def main():
                 out['vs_1gpu'] = None
             out['scaling_series'] = ('BASELINE config 5, strong scaling: this line\'s `value` at n_gpus > 1; at n_gpus = 1 the default line reports config 2 as '
                                      '`value` (the configuration the metric is quoted on, it fits one GPU) and config 5 on one GPU under `sharded_config`')
-            if rep is not None:
+            if rep is not None and rep.get('value') is not None:
                 out['replicas_c2'] = {k: rep[k] for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'scaling', 'config', 'l2_error') if k in rep}
     elif args.sharded_path or args.workload == 'c5':
         out = run_sharded(args, args.workload if args.workload != 'auto' else 'c2')
