@@ -734,7 +734,8 @@ def run_system(args, workload, steps=None, warmup=None):
                       'stacked_rows': rows, 'kernel': P['kernel'], 'kernel_parameter': P['kp'], 'nugget': P['nugget'], 'nugget_type': 'adaptive',
                       'reference_gn_steps': P['gn_steps'],
                       'schedule': ('leading-zero layout (unknowns interleaved by collocation point: staircase of slope 1/3)' if workload == 'c3' else
-                                   'Darcy: two factors + data rows stacked; ' + os.environ.get('GPK_BENCH_DARCY_NOTE', 'see DESIGN section 4'))},
+                                   'Darcy: a-part, u-part and data rows stacked; leading-zero layout with the unknowns ordered v1, v2, w1, w2, w0, v0 -- a '
+                                   'piecewise staircase for the u-part, a slope-1 staircase on a column sub-range for the a-part (DESIGN section 4)')},
            'l2_error': dict(err, gn_steps_run=warmup + steps, loss_first=losses[0], loss_last=losses[-1]),
            'f1_tflops': dense * steps / elapsed / 1e12,
            'phases_ms_per_step': {'trsm': solve_ms, 'syrk_and_potrf_H': phase_ms, 'syrk_launches_sum': prod_ms, 'trsv_update': tail_ms,
