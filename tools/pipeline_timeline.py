@@ -16,12 +16,21 @@ for r in step[first_tn - 1:]:
     a, b = int(r['Start_Timestamp']), int(r['End_Timestamp']); nm = short(r['Kernel_Name'])
     if 'potrf_panel' in nm or 'k64' in nm: continue
     print(f"{(a - t0) / 1e3:8.1f} -> {(b - t0) / 1e3:8.1f} {(b - a) / 1e3:7.1f}  q{r['Queue_Id']} grid {int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']):5d} {nm}")
-pk = [r for r in step if 'potrf_panel' in r['Kernel_Name'] or 'k64' in r['Kernel_Name']]
-i = 0; blk = 0
-while i < len(pk):
-    grp = pk[i:i + 15]
-    a = int(grp[0]['Start_Timestamp']); b = int(grp[-1]['End_Timestamp'])
-    pan = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in grp if 'potrf_panel' in r['Kernel_Name']]
-    k64 = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in grp if 'k64' in r['Kernel_Name']]
-    print(f'chain blk {blk}: {(a - t0) / 1e3:8.1f} -> {(b - t0) / 1e3:8.1f} span {(b - a) / 1e3:7.1f}  panel avg {sum(pan) / len(pan):5.1f} k64 avg {sum(k64) / max(len(k64), 1):5.1f}')
-    i += 15; blk += 1
+# ---- per-queue summary of the phase (from the first product launch to the end of the last factorisation kernel): busy time = sum of
+#      kernel durations on that queue, span = first start to last end; the chain stream carries the panel kernels and their small updates
+phase = step[first_tn:]
+last_fact = max(i for i, r in enumerate(phase) if 'potrf_panel' in r['Kernel_Name'])
+phase = phase[:last_fact + 1]
+p0 = int(phase[0]['Start_Timestamp']); p1 = max(int(r['End_Timestamp']) for r in phase)
+print(f'\nphase (first product launch -> last panel kernel): {(p1 - p0) / 1e3:.1f} us')
+byq = {}
+for r in phase:
+    byq.setdefault(r['Queue_Id'], []).append(r)
+for q, rs in sorted(byq.items()):
+    busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rs) / 1e3
+    a = min(int(r['Start_Timestamp']) for r in rs); b = max(int(r['End_Timestamp']) for r in rs)
+    npan = sum(1 for r in rs if 'potrf_panel' in r['Kernel_Name'])
+    tpan = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rs if 'potrf_panel' in r['Kernel_Name']) / 1e3
+    tn = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in rs if re.search(r'gemm_f64_kernel<\d+, \d+, \d+, \d+, true, false', r['Kernel_Name'])) / 1e3
+    print(f'queue {q}: {len(rs):4d} kernels, busy {busy:7.1f} us of a {(b - a) / 1e3:7.1f} us span ({(a - p0) / 1e3:7.1f} -> {(b - p0) / 1e3:7.1f}); '
+          f'products (TN) {tn:7.1f} us, {npan} panel kernels {tpan:7.1f} us')
