@@ -215,6 +215,37 @@ def test_darcy_leading_zero_layout_agrees_with_dense_schedule(Nd, Nb, Ndata):
     ctx.close()
 
 
+def test_darcy_steps_are_bitwise_reproducible():
+    """The Darcy step in the leading-zero layout (piecewise profile in the solve, two product launches, one-stream factorisation of the
+    order-6601 H): the same three steps from the same start, five times -- the bits must not depend on how the workgroups arrive."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(31)
+    Nd, Nb, Ndata = 1100, 150, 60
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    data = 0.05 * rng.normal(size=Ndata)
+    Tu, _ = ctx.assemble('Darcy_u', 'Gaussian', 0.2, Xd, Xb, 1e-7, 'adaptive')
+    Ta, _ = ctx.assemble('Darcy_a', 'Gaussian', 0.2, Xd, Xb, 1e-7, 'adaptive')
+    assert ctx.potrf(Tu) == 0 and ctx.potrf(Ta) == 0
+    prob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, np.ones(Nd), np.zeros(Nb), Tu, p0=1e-3, data_u=data, L2=Ta)
+    z0 = 0.3 * rng.normal(size=6 * Nd)
+    ref = None
+    for _ in range(5):
+        z = ctx.array(z0)
+        losses = []
+        for _ in range(3):
+            loss, info = ctx.gn_step(prob, z)
+            assert info == 0
+            losses.append(loss)
+        out = z.download().copy()
+        z.free()
+        if ref is None:
+            ref = (out, losses)
+        else:
+            assert np.array_equal(out, ref[0]) and losses == ref[1]
+    ctx.close()
+
+
 @pytest.mark.parametrize('n', [64, 65, 130, 1000, 2049, 4001])
 def test_fused_panel_schedule_matches_separate_update_launches(n):
     """gpk_debug_set(48, .): the rank-64 work between two Cholesky panels rides inside the panel kernels (default: part B at the
