@@ -5,17 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-`value` is measured on BASELINE config 2 (N_domain=4000, N_boundary=400; the configuration the metric is quoted on, it
-fits one GPU) at every N: one GPU solves it in ~10 ms per step, sharding it further is latency-dominated (SURVEY 8e:
-"replicas only"), so with N ranks each rank runs its own independent solve (weak scaling, no data-path collective) and
-value = N * K / max-over-ranks time.  The north-star SHARDED configuration (BASELINE config 5: N_domain=16000,
-N_boundary=2000, Theta of order 34000) runs right after, over the same N ranks -- panel-sharded Cholesky + column-
-sharded Gauss-Newton step over RCCL -- and is reported in the same JSON line under `sharded_config` (its N = 1, 2, 4, 8
-values form the strong-scaling curve of BASELINE config 5; `--workload c5` makes it the primary value instead).
+`value` at N = 1 is measured on BASELINE config 2 (N_domain=4000, N_boundary=400: the configuration the metric is quoted on, it
+fits one GPU); with N > 1 ranks `value` is the SHARDED BASELINE config 5 (N_domain=16000, Theta of order 34000: panel-sharded
+Cholesky + column-sharded Gauss-Newton step over RCCL, strong scaling) -- `value_workload` ("c2" / "c5") says which, machine-readably,
+and a sharded run that does not complete leaves `value: null`, never another workload's figure.  Config 5 on ONE GPU (the 1-GPU
+point of that series) is in every N = 1 line under `sharded_config`; N independent config-2 replicas in every N > 1 line under
+`replicas_c2`.
+
+The LAST stdout line is compact (bench_line.py, ~5 KB: contract fields, roofline, cpu_baseline, parity, one small object per
+secondary workload); the full result object goes to bench_detail.json and stderr.
 
 A "step" is one Gauss-Newton step of the reference's GN_method (src/PDEs.py:117-127): Hessian_GN + grad_loss + linear
-solve + update + one loss evaluation, executed as TRSM (n_z+1 right-hand sides) + SYRK + Cholesky of H + triangular
-solve, all operands resident in HBM.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
+solve + update + one loss evaluation, executed as the product's default sequence gpk_gn_step (TRSM with n_z+1 right-hand sides +
+SYRK + Cholesky of H + triangular solve) followed by gpk_gn_loss of the new iterate, all operands resident in HBM.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
 Rank 0 prints ONE JSON line.  `roofline.achieved` is measured live with HIP events recorded inside the timed steps on
 the stream the kernels run on; `roofline.traffic` is read from the newest stored PMC pass under profiles/ and says so
 (`traffic_source`); `cpu_baseline` times the CPU oracle (reference operation sequence) on this box's host cores.
@@ -49,6 +51,8 @@ WORKLOADS = {
     'c3': (2000, 400, 8, 'Burgers1d anisotropic_Gaussian sigma=[0.3,0.05] N_domain=2000 N_boundary=400 (->399) nugget 1e-5 seed 0 (BASELINE config 3)'),
     'c4': (1600, 200, 8, 'DarcyFlow2d inverse problem Gaussian sigma=0.2 N_domain=1600 N_boundary=200 N_data=60 noise=1e-3 nugget 1e-8 seed 9999 (BASELINE config 4)'),
 }
+TIMED_SEQUENCE = {True: 'gpk_gn_step + gpk_gn_loss per step (the product default: src/PDEs.py _gn_iterate)',
+                  False: 'gpk_gn_step alone (GPK_INSTEP_LOSS=1: loss taken from the step)'}
 PARITY_TOL = 1e-6                 # north star: device iterate within 1e-6 relative of the reference path on the same points
 SIGMA, ALPHA, M_EXP = 0.2, 1.0, 3.0
 
@@ -173,6 +177,26 @@ def stored_pmc_traffic(which='syrk', workload='c2'):
     return None, f'no stored PMC pass for workload {workload}'
 
 
+def emit(out):
+    """The full result object -> bench_detail.json (repo root; also gpurun_out/ when that exists, so that it travels back from a GPU
+    box) and stderr; the LAST stdout line is its compact form (bench_line.compact: <= ~5 KB, the driver keeps an 8 KB tail)."""
+    import bench_line
+    text = json.dumps(out, indent=1, default=str)
+    for d in ([os.environ['GPK_BENCH_DETAIL_DIR']] if os.environ.get('GPK_BENCH_DETAIL_DIR') else [ROOT, os.path.join(ROOT, 'gpurun_out')]):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, 'bench_detail.json'), 'w') as fh:
+                    fh.write(text + '\n')
+            except OSError:
+                pass
+    print('bench.py: full result object (also in bench_detail.json):\n' + json.dumps(out, default=str), file=sys.stderr, flush=True)
+    try:                                                          # RCCL prints a version banner through C stdio (fully buffered when stdout is
+        C.CDLL(None).fflush(None)                                 # a pipe): flush it NOW so that the JSON line is the last thing on stdout
+    except Exception:                                             # noqa: BLE001
+        pass
+    print(bench_line.compact(out), flush=True)
+
+
 class AbortWatch:
     """Keeps the primary result alive while the SECONDARY (sharded) run is in flight.
     * N > 1 ranks: a rank that fails in the middle of that run cannot tell peers that are blocked inside a collective -- they
@@ -200,7 +224,7 @@ class AbortWatch:
         with self.lock:                                           # never released: the process ends inside
             if self.rank == 0 and self.out is not None:
                 self.out['sharded_config'] = {'error': msg}
-                print(json.dumps(self.out), flush=True)
+                emit(self.out)
             sys.stdout.flush(); sys.stderr.flush()
             # exit code: 0 keeps a launcher (torchrun tears the job down on the first non-zero exit) from discarding the line rank 0
             # has just printed; GPK_BENCH_STRICT_EXIT=1 makes every rank that abandons the secondary run leave with 3 instead
@@ -313,16 +337,32 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     z = ctx.array(z0)
     prob.workspace()
     dev_first = first_step_on_device(ctx, prob, z0)               # for `parity` (also the first, code-object-loading step)
-    losses = []
+    # A timed step is what the product's GN_method executes per iteration (nonlinpdes-gpsolver_amd/src/PDEs.py, _gn_iterate; the
+    # reference's src/PDEs.py:117-127): gpk_gn_step, then gpk_gn_loss of the new iterate (true substitution).  GPK_INSTEP_LOSS=1 -- the
+    # product's labelled variant that takes the loss gpk_gn_step returns for free -- drops the second call here as it does there.
+    with_loss = os.environ.get('GPK_INSTEP_LOSS', '0') != '1'
+    losses = [ctx.gn_loss(prob, z)]
+    loss_s = 0.0
+
+    def product_step(timed=False):
+        nonlocal loss_s
+        l_in = ctx.gn_step(prob, z)[0]
+        if not with_loss:
+            return l_in
+        t1 = time.perf_counter()
+        l_new = ctx.gn_loss(prob, z)                               # (both calls end with a host synchronisation: host clocks are exact)
+        if timed:
+            loss_s += time.perf_counter() - t1
+        return l_new
     for _ in range(args.warmup):
-        losses.append(ctx.gn_step(prob, z)[0])
+        losses.append(product_step())
     ctx.prof_enable(True)
     ctx.synchronize(); torch.cuda.synchronize()
     if comm is not None:
         comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(ctx.gn_step(prob, z)[0])
+        losses.append(product_step(True))
     ctx.synchronize(); torch.cuda.synchronize()
     if comm is not None:
         comm.barrier()
@@ -331,7 +371,8 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
         elapsed = comm.max_float(elapsed, torch.device('cuda', local))
     prof = ctx.prof_read()
     ctx.prof_enable(False)
-    losses.append(ctx.gn_loss(prob, z))
+    if not with_loss:
+        losses.append(ctx.gn_loss(prob, z))
 
     # accuracy half of the metric
     sol = z.download()
@@ -378,6 +419,7 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
                                    f'{world} independent replicas of the workload, one per GPU (no data-path collective); the '
                                    f'sharded north-star configuration is reported under sharded_config'),
                    'kernel': 'Gaussian', 'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive',
+                   'timed_sequence': TIMED_SEQUENCE[with_loss],
                    'formulation': 'TRSM(n_z+1 rhs) + SYRK + POTRF(H) + TRSV every step.  Nothing that depends on the iterate is cached '
                                   'across steps; what IS computed once per factor and reused by every step (like the factor L itself) are the '
                                   f'inverses of the {dinv_block}-row diagonal blocks of L (gpk_trtri_diag, block size gpk.device.dinv_block_for(N); '
@@ -390,6 +432,7 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
         'f1_tflops': world * f1_flops(N, nz) * args.steps / elapsed / 1e12,
         'phases_ms_per_step': {'trsm': prof['trsm_ms'] / steps, 'syrk_and_potrf_H': phase_ms,
                                'syrk_launches_sum': syrk_ms, 'trsv_update': prof['trsv_update_ms'] / steps,
+                               'loss_call': 1e3 * loss_s / args.steps if with_loss else 0.0,
                                'pipelined': bool(pipelined), 'chain_partition_cus': prof['chain_cus'] if pipelined else 0},
         'one_time_ms': {'assembly': asm_ms, 'cholesky_theta': chol_ms, 'cholesky_theta_first_call': chol_first_ms, 'diagonal_block_inverses': dinv_ms,
                         'diagonal_block_rows': dinv_block},
@@ -691,19 +734,33 @@ def run_system(args, workload, steps=None, warmup=None):
     prob.workspace()
     dev_first = first_step_on_device(ctx, prob, z0)
     z = ctx.array(z0)
-    losses = []
+    with_loss = os.environ.get('GPK_INSTEP_LOSS', '0') != '1'       # (as in run_single: the product's per-iteration sequence)
+    losses = [ctx.gn_loss(prob, z)]
+    loss_s = 0.0
+
+    def product_step(timed=False):
+        nonlocal loss_s
+        l_in = ctx.gn_step(prob, z)[0]
+        if not with_loss:
+            return l_in
+        t1 = time.perf_counter()
+        l_new = ctx.gn_loss(prob, z)
+        if timed:
+            loss_s += time.perf_counter() - t1
+        return l_new
     for _ in range(warmup):
-        losses.append(ctx.gn_step(prob, z)[0])
+        losses.append(product_step())
     ctx.prof_enable(True)
     ctx.synchronize(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses.append(ctx.gn_step(prob, z)[0])
+        losses.append(product_step(True))
     ctx.synchronize(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = ctx.prof_read()
     ctx.prof_enable(False)
-    losses.append(ctx.gn_loss(prob, z))
+    if not with_loss:
+        losses.append(ctx.gn_loss(prob, z))
     n = max(prof['steps'], 1)
     sol = z.download()
     # ---- accuracy against the independent truths (the drivers' test grids)
@@ -732,14 +789,14 @@ def run_system(args, workload, steps=None, warmup=None):
     out = {'value': steps / elapsed, 'unit': 'GN steps/s', 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * elapsed / steps,
            'config': {'workload': P['desc'], 'N_domain': Nd, 'N_boundary': Nb, 'theta_orders': [T.rows for T in factors], 'unknowns': nz,
                       'stacked_rows': rows, 'kernel': P['kernel'], 'kernel_parameter': P['kp'], 'nugget': P['nugget'], 'nugget_type': 'adaptive',
-                      'reference_gn_steps': P['gn_steps'],
+                      'reference_gn_steps': P['gn_steps'], 'timed_sequence': TIMED_SEQUENCE[with_loss],
                       'schedule': ('leading-zero layout (unknowns interleaved by collocation point: staircase of slope 1/3)' if workload == 'c3' else
                                    'Darcy: a-part, u-part and data rows stacked; leading-zero layout with the unknowns ordered v1, v2, w1, w2, w0, v0 -- a '
                                    'piecewise staircase for the u-part, a slope-1 staircase on a column sub-range for the a-part (DESIGN section 4)')},
            'l2_error': dict(err, gn_steps_run=warmup + steps, loss_first=losses[0], loss_last=losses[-1]),
            'f1_tflops': dense * steps / elapsed / 1e12,
            'phases_ms_per_step': {'trsm': solve_ms, 'syrk_and_potrf_H': phase_ms, 'syrk_launches_sum': prod_ms, 'trsv_update': tail_ms,
-                                  'pipelined': bool(prof['pipelined'])},
+                                  'loss_call': 1e3 * loss_s / steps if with_loss else 0.0, 'pipelined': bool(prof['pipelined'])},
            'one_time_ms': dict(one_time, diagonal_block_inverses=dinv_ms, diagonal_block_rows=prob.struct.dinv_block),
            'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel<.., NN> = the solve phase S = L^{-1}[A | F] of every factor',
                         'achieved': tf(solve_fl, solve_ms), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf(solve_fl, solve_ms) / FP64_MFMA_PEAK_TFLOPS,
@@ -815,6 +872,30 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
             engine_note = f' (native executor unavailable on some rank{": " + err if err else ""}; fell back)'
         elif err:
             raise RuntimeError(err)
+    # First contact with the fabric (N > 1, native executor): bandwidth of the BOUND ncclBroadcast / ncclAllGather on one panel-sized
+    # buffer (34000 x 512 doubles = 139 MB) per root, and how many ranks the communicator delivers -- so that a slow curve can be
+    # read from the line (GB/s per link against ~153 GB/s of one xGMI link) instead of guessed.
+    preflight = None
+    wall = {}
+    t_run0 = time.perf_counter()
+    if mgpu and world > 1 and os.environ.get('GPK_BENCH_PREFLIGHT', '1') == '1':
+        try:
+            preflight = mgpu.preflight(int(os.environ.get('GPK_PREFLIGHT_BYTES', str(139 * 2 ** 20))), 2)
+        except Exception as e:                                    # noqa: BLE001 -- reported; a failing collective fails the run below anyway
+            preflight = {'error': f'{type(e).__name__}: {e}'}
+        wall['preflight_s'] = time.perf_counter() - t_run0
+    # the A/B probes below share ONE wall budget (GPK_PROBE_BUDGET_S, default 90 s): before every probe all ranks agree (max over ranks)
+    # on the time spent so far; past the budget the remaining probes are skipped and the defaults kept -- replicas + sharded run + solo
+    # run + CPU parity then fit inside GPK_SHARDED_TIMEOUT by construction
+    probe_budget = float(os.environ.get('GPK_PROBE_BUDGET_S', '90'))
+    t_probe = [0.0]
+
+    def probe_allowed(name):
+        spent = comm.max_float(t_probe[0], dev) if world > 1 else t_probe[0]
+        if spent > probe_budget:
+            mode_probe.setdefault('skipped_over_budget', []).append(name)
+            return False
+        return True
     Xd, Xb, f, g, z0 = synthetic_problem(Nd, Nb)                  # identical on every rank (seeded)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
     tXd, tXb, tf, tg, z = t(Xd), t(Xb), t(f), t(g), t(z0)
@@ -856,7 +937,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
     chol_first_ms = chol_ms                                       # (first factorisation of the process: code objects, buffers)
     if world == 1:
         _, chol_ms, _ = factor_once()
-    if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1':
+    if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1' and probe_allowed('cholesky_theta'):
         # More than one rank: the factorisation is timed with BOTH plans -- look-ahead (default) and the strictly sequential
         # factor -> broadcast -> update -- and the faster one (max over ranks, so every rank decides alike) is kept for what
         # follows; both times are reported.  (Look-ahead hides broadcasts behind updates but its panel kernels share the CUs
@@ -865,9 +946,11 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
         # is reported as one_time_ms.cholesky_theta_first_call; both plans are timed WARM here: one untimed run of the sequential plan,
         # then look-ahead and sequential once each)
         chol_first_ms = chol_ms
+        tp0 = time.perf_counter()
         set_mode(lookahead=0); factor_once()
         set_mode(lookahead=1); _, c1, info1 = factor_once()
         set_mode(lookahead=0); _, c2, info2 = factor_once()
+        t_probe[0] += time.perf_counter() - tp0
         mode_probe['cholesky_theta_ms'] = {'lookahead': c1, 'sequential': c2, 'first_call_lookahead': chol_first_ms}
         if c2 < c1 and info2 == info:
             chol_ms = c2
@@ -892,51 +975,63 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
     S2 = torch.zeros((N, lds), dtype=torch.float64, device=dev)
     ps.Dinv, ps.Dinv2, ps.dinv_block = Dinv.data_ptr(), None, gpk.device.dinv_block_for(N)
     if mgpu:
-        step = lambda: mgpu.gn_step(ps, z.data_ptr(), 1.0, S.data_ptr(), lds, S2.data_ptr(), Hb.data_ptr(), lds, delta.data_ptr())[0]
+        step_only = lambda: mgpu.gn_step(ps, z.data_ptr(), 1.0, S.data_ptr(), lds, S2.data_ptr(), Hb.data_ptr(), lds, delta.data_ptr())[0]
     else:
-        step = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
+        step_only = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
+    # the timed step is the product's per-iteration sequence here too: the (collective) step, then the loss of the new iterate by true
+    # substitution with the factor every rank holds (replicated: one vector; src/PDEs.py:117-127 of the reference)
+    with_loss = os.environ.get('GPK_INSTEP_LOSS', '0') != '1'
+
+    def loss_of_iterate():
+        w = torch.cat([ALPHA * z ** M_EXP - tf, z, tg])           # F(z), src/PDEs.py:84-85 of the reference
+        ops.trsv(Theta, N, w, False)
+        return float((w * w).sum().item())
+
+    def step():
+        l_in = step_only()
+        return loss_of_iterate() if with_loss else l_in
     # first step from z0 for `parity` (every rank takes part: the step is collective; it is also the untimed first step that pays
     # the one-time allocations of the executor); the iterate is then reset to z0
-    loss0_dev = step()
+    loss0_dev = step_only()
     z1_dev = z.cpu().numpy().copy()
-    w1 = t(np.concatenate([ALPHA * z1_dev ** M_EXP - f, z1_dev, g]))          # F(z1), src/PDEs.py:84-85 of the reference
-    ops.trsv(Theta, N, w1, False)                                 # loss(z1) = || L^{-1} F(z1) ||^2 by true substitution
-    loss1_dev = float((w1 * w1).sum().item())
+    loss1_dev = loss_of_iterate()                                 # loss(z1) = || L^{-1} F(z1) ||^2 by true substitution
     z.copy_(t(z0))
     losses = []
+    warmup_run = 0
     if world > 1 and os.environ.get('GPK_BENCH_MODE_PROBE', '1') == '1':
-        # the same for the Cholesky of the bordered Gauss-Newton matrix: one untimed-for-the-metric step each with the replicated
-        # and with the panel-sharded factorisation, the faster one kept (all ranks alike); these two steps count as warm-up
-        times = {}
-        for name, flag in (('replicated', 0), ('panel_sharded', 1), ('replicated', 0), ('panel_sharded', 1)):   # A/B/A/B: the first pair warms both up
-            set_mode(shard_hb=flag)
-            comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-            losses.append(step())
-            torch.cuda.synchronize()
-            times[name] = comm.max_float(1e3 * (time.perf_counter() - t0), dev)
-        set_mode(shard_hb=int(times['panel_sharded'] < times['replicated']))
-        mode_probe['step_ms_by_cholesky_of_Hb'] = times
-        mode_probe['shard_hb_kept'] = bool(solver.shard_hb)
-        warmup_run = 4
-        if mgpu:
-            # and for the exchange of the column shards of S: one all-gather, or one broadcast per shard on the communication stream with
-            # the block-row products of Hb issued behind the arrivals (native executor only; both once to warm up, then once timed)
-            xt = {}
-            for name, flag in (('all_gather', 0), ('broadcasts_chased_by_products', 1)) * 2:
-                set_mode(overlap_s=flag)
+        # the same for the Cholesky of the bordered Gauss-Newton matrix: ONE A/B pair, each variant run twice (the first run of a variant
+        # pays its one-time allocations and is not the one compared), the faster one kept (all ranks alike); these steps count as warm-up
+        def ab(names_flags, setter):
+            nonlocal warmup_run
+            times = {}
+            tp0 = time.perf_counter()
+            for name, flag in names_flags * 2:
+                setter(flag)
                 comm.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-                losses.append(step())
+                losses.append(step_only())
                 torch.cuda.synchronize()
-                xt[name] = comm.max_float(1e3 * (time.perf_counter() - t0), dev)
+                times[name] = comm.max_float(1e3 * (time.perf_counter() - t0), dev)
+                warmup_run += 1
+            t_probe[0] += time.perf_counter() - tp0
+            return times
+        if probe_allowed('cholesky_of_Hb'):
+            times = ab((('replicated', 0), ('panel_sharded', 1)), lambda f: set_mode(shard_hb=f))
+            set_mode(shard_hb=int(times['panel_sharded'] < times['replicated']))
+            mode_probe['step_ms_by_cholesky_of_Hb'] = times
+        mode_probe['shard_hb_kept'] = bool(solver.shard_hb)
+        if mgpu and probe_allowed('exchange_of_S'):
+            # and for the exchange of the column shards of S: one all-gather, or one broadcast per shard on the communication stream with
+            # the block-row products of Hb issued behind the arrivals (native executor only)
+            xt = ab((('all_gather', 0), ('broadcasts_chased_by_products', 1)), lambda f: set_mode(overlap_s=f))
             keep = int(xt['broadcasts_chased_by_products'] < xt['all_gather'])
             set_mode(overlap_s=keep)
             mode_probe['step_ms_by_exchange_of_S'] = xt
             mode_probe['overlap_s_kept'] = bool(keep)
-            warmup_run += 4
-    else:
-        for _ in range(warmup):
-            losses.append(step())
-        warmup_run = warmup
+        mode_probe['probe_wall_s'] = t_probe[0]
+    for _ in range(max(warmup - warmup_run, 0)):
+        losses.append(step())
+        warmup_run += 1
+    wall['setup_and_probes_s'] = time.perf_counter() - t_run0
     comm.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -980,6 +1075,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': desc, 'N_domain': Nd, 'N_boundary': Nb, 'theta_order': N, 'unknowns': nz, 'kernel': 'Gaussian',
                        'kernel_parameter': SIGMA, 'nugget': nugget, 'nugget_type': 'adaptive', 'seed': 0,
+                       'timed_sequence': TIMED_SEQUENCE[with_loss].replace('gpk_gn_step', 'gpk_mg_gn_step' if mgpu else 'sharded gn_step'),
                        'parallelism': solver.describe(world, gpk.device.dinv_block_for(N)),
                        'executor': (f'native: gpk_mg_potrf / gpk_mg_gn_step (C ABI), collectives = {getattr(mgpu, "comm_kind", "none (one rank)")}'
                                     if mgpu else 'python: gpk/sharded.py over torch.distributed' + engine_note),
@@ -990,7 +1086,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
             'f1_tflops': rate,
             'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'cholesky_theta_first_call': chol_first_ms, 'diagonal_block_inverses': dinv_ms},
-            'mode_probe': mode_probe or None,
+            'mode_probe': mode_probe or None, 'preflight': preflight, 'wall_s': wall,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step: solve + product + Cholesky of Hb), flops EXECUTED summed over the ranks',
                          'achieved': ex_rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
                          'frac': ex_rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': None,
@@ -1071,14 +1167,20 @@ def main():
         rep = None
         if not args.no_replicas:
             rep = run_single(args, 'c2', Comm())
+        # what survives if the sharded run fails or hangs: a line whose `value` is NULL (the key means "sharded config 5" at N > 1 --
+        # `value_workload` says so machine-readably -- and is never filled with another workload's figure); the replicas' aggregate
+        # stays readable under replicas_c2
+        fb = None
+        if rank == 0:
+            fb = {'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points', 'value': None, 'unit': 'GN steps/s',
+                  'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'strong',
+                  'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'value_workload': 'c5',
+                  'config': {'workload': WORKLOADS['c5'][3], 'parallelism': f'sharded over {world} ranks (did not complete)'},
+                  'fallback': 'the sharded BASELINE config 5 run did not complete (see sharded_config.error): value is null; the aggregate of the '
+                              'N independent config-2 replicas measured before it is under replicas_c2'}
             if rep is not None:
-                rep['fallback'] = ('the sharded BASELINE config 5 run did not complete (see sharded_config.error): `value` is the aggregate of N '
-                                   'independent config-2 replicas, NOT the strong-scaling figure')
-        if rep is None and rank == 0:                             # (--no-replicas: still leave ONE line behind if the sharded run dies)
-            rep = {'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points', 'value': None, 'unit': 'GN steps/s',
-                   'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': True, 'scaling': 'strong',
-                   'fallback': 'the sharded BASELINE config 5 run did not complete (see sharded_config.error) and the replicas were skipped'}
-        watch = AbortWatch(rank, rep, use_store=True)
+                fb['replicas_c2'] = {k: rep[k] for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'scaling', 'config', 'l2_error', 'roofline') if k in rep}
+        watch = AbortWatch(rank, fb, use_store=True)
         solo = None
         try:
             out = run_sharded(args, 'c5')
@@ -1099,36 +1201,47 @@ def main():
             else:
                 out['one_gpu_same_job'] = solo
                 out['vs_1gpu'] = None
+            out['value_workload'] = 'c5'
             out['scaling_series'] = ('BASELINE config 5, strong scaling: this line\'s `value` at n_gpus > 1; at n_gpus = 1 the default line reports config 2 as '
                                      '`value` (the configuration the metric is quoted on, it fits one GPU) and config 5 on one GPU under `sharded_config`')
             if rep is not None and rep.get('value') is not None:
                 out['replicas_c2'] = {k: rep[k] for k in ('value', 'unit', 'n_gpus', 'ms_per_step', 'scaling', 'config', 'l2_error') if k in rep}
     elif args.sharded_path or args.workload == 'c5':
         out = run_sharded(args, args.workload if args.workload != 'auto' else 'c2')
+        if out is not None:
+            out['value_workload'] = args.workload if args.workload != 'auto' else 'c2'
     elif args.workload in ('c3', 'c4'):
         out = contract_line(run_system(args, args.workload), 1, 'weak')
+        out['value_workload'] = args.workload
     else:
         workload = args.workload if args.workload != 'auto' else 'c2'
         from gpk.sharded import Comm
         out = run_single(args, workload, Comm() if world > 1 else None)
+        if out is not None:
+            out['value_workload'] = workload
+        # GPK_BENCH_SECONDARY_CPU=0: the CPU oracle legs (cpu_baseline + parity) of the SECONDARY workloads are skipped -- the
+        # primary workload keeps its own; used by the -m gpu test of the default command, which checks the line, not the CPU
+        sec_args = args
+        if os.environ.get('GPK_BENCH_SECONDARY_CPU', '1') == '0':
+            sec_args = argparse.Namespace(**vars(args)); sec_args.no_cpu_baseline = True
         if args.workload == 'auto' and world == 1 and not args.no_n10k:
             # north-star target size (N_domain = 10^4 on ONE GPU, >= 10x vs the CPU reference sequence): a secondary object of the
             # same line, its own CPU baselines beside it (B1 = reference operation sequence, ~1 min on the host cores; B2 = triangular)
             try:
-                nk = run_single(args, 'n10k', None, secondary=True, steps=min(args.steps, 4), warmup=1)
+                nk = run_single(sec_args, 'n10k', None, secondary=True, steps=min(args.steps, 4), warmup=1)
                 out['n10k'] = pick(nk)
             except Exception as e:                                # noqa: BLE001 -- reported, the primary value survives
                 out['n10k'] = {'error': f'{type(e).__name__}: {e}'}
         if args.workload == 'auto' and world == 1 and not args.no_c3c4:
             for name in ('c3', 'c4'):                             # BASELINE configs 3 and 4 under the same clock
                 try:
-                    out[name] = run_system(args, name)
+                    out[name] = run_system(sec_args, name)
                 except Exception as e:                            # noqa: BLE001 -- reported, the primary value survives
                     out[name] = {'error': f'{type(e).__name__}: {e}'}
         if args.workload == 'auto' and not args.no_sharded_config:
             watch = AbortWatch(rank, out, use_store=use_pg)
             try:                                                  # the value above must survive a failure of the secondary run
-                sh = run_sharded(args, 'c5', steps=min(args.steps, 3), warmup=1)
+                sh = run_sharded(sec_args, 'c5', steps=min(args.steps, 3), warmup=1)
                 if out is not None and sh is not None:
                     out['sharded_config'] = pick(sh)
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
@@ -1149,11 +1262,7 @@ def main():
     # the ONE line goes out before anything that can still block (a peer that died after its last collective would otherwise
     # leave rank 0 in the final barrier with the result unprinted)
     if out is not None:
-        try:                                                      # RCCL prints a version banner through C stdio (fully buffered when stdout is
-            C.CDLL(None).fflush(None)                             # a pipe): flush it NOW so that the JSON line is the last thing on stdout
-        except Exception:                                         # noqa: BLE001
-            pass
-        print(json.dumps(out), flush=True)
+        emit(out)
         if bad:
             print(f'bench.py: PARITY FAILURE -- device iterate further than {PARITY_TOL:g} (relative) from the CPU oracle in: {", ".join(bad)}',
                   file=sys.stderr, flush=True)

@@ -67,6 +67,12 @@ int gpk_mg_set_option(gpk_mg_handle mg, int key, int value);
  * verified on the host; *host_ok = 1 if both delivered what they should. */
 int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok);
 
+/* Bandwidth preflight of the bound collectives (every rank calls it, before the first large run on an unknown fabric): `reps`
+ * broadcasts of `bytes` from every root in turn and `reps` all-gathers of bytes / world per rank, each after one untimed warm-up,
+ * timed with HIP events.  host_bcast_ms[world]: average ms per broadcast and root; *host_allgather_ms: average ms per all-gather;
+ * *host_ranks_seen: distinct ranks the all-gather delivered (== world when the communicator spans the job). */
+int gpk_mg_preflight(gpk_mg_handle mg, size_t bytes, int reps, double* host_bcast_ms, double* host_allgather_ms, int* host_ranks_seen);
+
 /* gpk_potrf over all ranks: A (n x n, ld lda) holds the SAME symmetric matrix on every rank on entry and the complete
  * lower factor on every rank on return.  host_info: LAPACK info, identical on all ranks (one host read at the end). */
 int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info);

@@ -450,6 +450,69 @@ extern "C" int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok) {
     return 0;
 }
 
+// Bandwidth preflight of the bound collectives on buffers of the size the schedule moves (bench.py, before the first timed run on a
+// fabric the code has never seen): `reps` broadcasts of `bytes` from every root in turn and `reps` all-gathers of bytes / world per
+// rank, each after one untimed warm-up call, timed with HIP events on the handle's stream.  host_bcast_ms[world]: average
+// milliseconds of one broadcast per root; *host_allgather_ms: average of one all-gather; *host_ranks_seen: how many DISTINCT ranks
+// the all-gather delivered (each rank contributes its rank id) -- must equal world.
+extern "C" int gpk_mg_preflight(gpk_mg_handle mg, size_t bytes, int reps, double* host_bcast_ms, double* host_allgather_ms, int* host_ranks_seen) {
+    if (!mg || !host_bcast_ms || !host_allgather_ms || !host_ranks_seen || reps < 1 || bytes < 8) return GPK_ERR_ARG;
+    gpk_handle h = mg->h;
+    if (!mg->bcast || !mg->allgather) return gpk_bad_arg(h, "gpk_mg_preflight: no communicator bound");
+    const int P = mg->world;
+    const size_t n = bytes / sizeof(double), per = std::max<size_t>(n / P, 1);
+    double* d = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&d, (n + per * (P + 1)) * sizeof(double)));
+    double* gs = d + n;
+    double* gr = gs + per;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, (n + per * (P + 1)) * sizeof(double), h->stream);
+    const double me = (double)mg->rank;
+    if (e == hipSuccess) e = hipMemcpyAsync(gs, &me, sizeof(double), hipMemcpyHostToDevice, h->stream);
+    for (int root = 0; root < P && rc == 0 && e == hipSuccess; ++root) {
+        int r = mg->bcast(d, d, n, NCCL_DOUBLE, root, mg->comm, (void*)h->stream);            // warm-up (connection set-up of this root)
+        if (r == 0) e = hipEventRecord(e0, h->stream);
+        for (int i = 0; i < reps && r == 0; ++i) r = mg->bcast(d, d, n, NCCL_DOUBLE, root, mg->comm, (void*)h->stream);
+        if (r != 0) { rc = nccl_fail(mg, r, "preflight broadcast"); break; }
+        if (e == hipSuccess) e = hipEventRecord(e1, h->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        host_bcast_ms[root] = (double)ms / reps;
+    }
+    if (rc == 0 && e == hipSuccess) {
+        int r = mg->allgather(gs, gr, per, NCCL_DOUBLE, mg->comm, (void*)h->stream);
+        if (r == 0) e = hipEventRecord(e0, h->stream);
+        for (int i = 0; i < reps && r == 0; ++i) r = mg->allgather(gs, gr, per, NCCL_DOUBLE, mg->comm, (void*)h->stream);
+        if (r != 0) rc = nccl_fail(mg, r, "preflight all-gather");
+        if (rc == 0 && e == hipSuccess) e = hipEventRecord(e1, h->stream);
+        if (rc == 0 && e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (rc == 0 && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        *host_allgather_ms = (double)ms / reps;
+    }
+    int seen = 0;
+    if (rc == 0 && e == hipSuccess) {
+        std::vector<char> mark(P, 0);
+        for (int r = 0; r < P && e == hipSuccess; ++r) {
+            double v = -1.0;
+            e = hipMemcpy(&v, gr + (size_t)r * per, sizeof(double), hipMemcpyDeviceToHost);
+            const int id = (int)v;
+            if (e == hipSuccess && v == (double)id && id >= 0 && id < P && !mark[id]) { mark[id] = 1; ++seen; }
+        }
+    }
+    *host_ranks_seen = seen;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return gpk_fail(h, e, "gpk_mg_preflight", __FILE__, __LINE__);
+    return 0;
+}
+
 extern "C" int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info) {
     if (!mg || !A || n < 0 || lda < n) return GPK_ERR_ARG;
     gpk_handle h = mg->h;

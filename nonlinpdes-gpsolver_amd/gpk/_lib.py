@@ -40,6 +40,7 @@ PROTOTYPES = {
     'gpk_mg_rccl_init': (_i, [_vp, C.c_char_p, _vp]),
     'gpk_mg_set_option': (_i, [_vp, _i, _i]),
     'gpk_mg_selftest': (_i, [_vp, _pi]),
+    'gpk_mg_preflight': (_i, [_vp, _sz, _i, _pd, _pd, _pi]),
     'gpk_mg_potrf': (_i, [_vp, _vp, _i, _i, _pi]),
     'gpk_mg_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _vp, _i, _vp, _pd, _pi]),
     'gpk_mg_plan_potrf': (_i, [_i, _i, _i, _i, _i, _pi, _i, _pi]),

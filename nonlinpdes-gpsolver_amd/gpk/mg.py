@@ -88,12 +88,18 @@ class MultiGpu:
         ctx._chk(self.lib.gpk_mg_create(ctx.h, self.rank, self.world, self.panel, C.byref(h)))
         self.h = h
         self._keep = []
-        if comm == 'rccl':                                         # (also with one rank when asked for: the binding and the self-test run)
-            self._init_rccl(group)
-        elif comm == 'staged':
-            self._init_staged(group)
-        elif self.world > 1:
-            raise ValueError("world > 1 needs comm='rccl' or comm='staged'")
+        try:
+            if comm == 'rccl':                                     # (also with one rank when asked for: the binding and the self-test run)
+                self._init_rccl(group)
+            elif comm == 'staged':
+                self._init_staged(group)
+            elif self.world > 1:
+                raise ValueError("world > 1 needs comm='rccl' or comm='staged'")
+        except BaseException:
+            # the object is never handed to the caller: release the native handle (and a half-made communicator) before re-raising
+            # (_init_rccl raises on EVERY rank by design when any rank cannot bind RCCL; a caller's fall-back must not leak it)
+            self.close()
+            raise
 
     # ---- communicators ------------------------------------------------------------------------------------------------
     def _init_rccl(self, group):
@@ -195,6 +201,19 @@ class MultiGpu:
         ok = C.c_int()
         self.ctx._chk(self.lib.gpk_mg_selftest(self.h, C.byref(ok)))
         return bool(ok.value)
+
+    def preflight(self, nbytes=139 * 2 ** 20, reps=2):
+        """Bandwidth of the BOUND collectives on a buffer of the size of one panel broadcast of BASELINE config 5 (34000 x 512 doubles =
+        139 MB): every rank calls it.  -> dict with GB/s per broadcast root, of the all-gather (bytes received per rank / time) and the
+        number of distinct ranks the all-gather delivered (gpk_mg_preflight)."""
+        bms = (C.c_double * self.world)()
+        ams, seen = C.c_double(), C.c_int()
+        self.ctx._chk(self.lib.gpk_mg_preflight(self.h, int(nbytes), int(reps), bms, C.byref(ams), C.byref(seen)))
+        gbs = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else None
+        per = max(nbytes // 8 // self.world, 1) * 8
+        return {'bytes': int(nbytes), 'reps': int(reps), 'bcast_ms_by_root': list(bms), 'bcast_gbs_by_root': [gbs(nbytes, m) for m in bms],
+                'allgather_ms': ams.value, 'allgather_gbs_received': gbs(per * (self.world - 1), ams.value) if self.world > 1 else None,
+                'ranks_seen_by_rccl': seen.value}
 
     def potrf(self, A_ptr, n, lda):
         """In-place lower Cholesky over all ranks (A replicated on entry, the full factor on every rank on return) -> info"""

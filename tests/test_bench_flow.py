@@ -1,8 +1,9 @@
 """Control flow of bench.py with N > 1 ranks, on CPU: two gloo processes, the GPU-touching functions replaced by stubs.
 Checks what the driver relies on: every rank takes part in both phases (replicas of config 2, then the sharded config 5),
-exactly ONE JSON line comes out (rank 0); since round 4 its `value` is the SHARDED config 5 (strong scaling) with the same
-configuration timed on rank 0 alone beside it (vs_1gpu) and the config-2 replicas as a secondary object -- and when the sharded
-run fails on one side, the replica line survives with the error attached."""
+exactly ONE JSON line comes out (rank 0), the compact one (bench_line.py; the full object goes to bench_detail.json); since round 4
+its `value` is the SHARDED config 5 (strong scaling, `value_workload` = "c5") with the same configuration timed on rank 0 alone beside
+it (vs_1gpu) and the config-2 replicas as a secondary object -- and when the sharded run fails on one side, a line survives with the
+error attached, `value` NULL (never another workload's figure under the same key, round 5) and the replicas under replicas_c2."""
 import json
 import os
 import socket
@@ -50,7 +51,7 @@ def test_two_rank_flow_prints_one_line(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), GPK_BENCH_BACKEND='gloo')
+                   MASTER_PORT=str(port), GPK_BENCH_BACKEND='gloo', GPK_BENCH_DETAIL_DIR=str(tmp_path))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=240) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
@@ -58,9 +59,13 @@ def test_two_rank_flow_prints_one_line(tmp_path):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['value'] == 3.0      # the sharded configuration IS the value
+    assert d['value_workload'] == 'c5' and len(lines[0]) < 7000
+    full = json.load(open(tmp_path / 'bench_detail.json'))       # the full object beside it
+    assert full['value'] == 3.0 and 'scaling_series' in full
     assert d['vs_1gpu'] == 1.5 and d['parallel_efficiency'] == 0.75 and d['one_gpu_same_job']['n_gpus'] == 1
     assert d['replicas_c2']['scaling'] == 'weak'
-    assert abs(d['replicas_c2']['value'] - 2 * 4 / 1.5) < 1e-9   # max over ranks of (0.5, 1.5)
+    assert abs(d['replicas_c2']['value'] - 2 * 4 / 1.5) < 1e-4   # max over ranks of (0.5, 1.5); the line carries 6 significant digits
+    assert abs(full['replicas_c2']['value'] - 2 * 4 / 1.5) < 1e-9
     assert d['parity_failed'] is None
 
 
@@ -91,14 +96,15 @@ def test_two_rank_flow_survives_a_one_sided_failure(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), GPK_BENCH_BACKEND='gloo')
+                   MASTER_PORT=str(port), GPK_BENCH_BACKEND='gloo', GPK_BENCH_DETAIL_DIR=str(tmp_path))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=120) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
     lines = [l for o in outs for l in o[0].splitlines() if l.startswith('{')]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d['value'] == 42.0 and d['n_gpus'] == 2 and 'NOT the strong-scaling figure' in d['fallback']
+    assert d['value'] is None and d['value_workload'] == 'c5' and d['n_gpus'] == 2 and 'did not complete' in d['fallback']
+    assert d['replicas_c2']['value'] == 42.0 and d['replicas_c2']['scaling'] == 'weak'
     assert 'out of memory (simulated)' in d['sharded_config']['error'] and 'rank 1' in d['sharded_config']['error']
 
 
@@ -136,7 +142,7 @@ def test_hanging_sharded_run_is_abandoned_at_the_deadline(tmp_path):
         sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--no-n10k', '--no-c3c4']
         bench.main()
     '''))
-    env = dict(os.environ, GPK_SHARDED_TIMEOUT='2')
+    env = dict(os.environ, GPK_SHARDED_TIMEOUT='2', GPK_BENCH_DETAIL_DIR=str(tmp_path))
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'GPK_FORCE_PG'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=120)
