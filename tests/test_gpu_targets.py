@@ -4,7 +4,9 @@ would need hours here -- SURVEY 8c, prompt (3)):
   * BASELINE config 5 -- NonLinElliptic2d, N_domain = 16000, N_boundary = 2000, Theta of order 34000 (9.2 GB) -- on ONE rank
     through the multi-GPU entry points (gpk_mg_potrf with the panel plan, gpk_mg_gn_step), i.e. the 1-GPU point of the
     scaling series bench.py reports;
-  * the north-star target size N_domain = 10000 (N_boundary = 1000, order 21000) through gpk_potrf / gpk_gn_step.
+  * the north-star target size N_domain = 10000 (N_boundary = 1000, order 21000) through gpk_potrf / gpk_gn_step;
+  * round 5: the first Gauss-Newton iterate of config 5 against the ORACLE on the device's factor (what bench.py reports as
+    sharded_config.parity), test_config5_first_iterate_against_the_oracle.
 
 Pinned per configuration: the nugget that was needed (the marginal-pivot hazard of SURVEY 7: min pivot ~8e-14 at order
 34000 with nugget 1e-13), LAPACK info = 0, rows of L L^T against rows of Theta recomputed from the closed forms (Laplacian
@@ -92,3 +94,66 @@ def test_large_configuration_on_one_gpu(name, Nd, Nb, engine):
     if mgpu:
         mgpu.close()
     ctx.close()
+
+
+def _host_mem_available_gb():
+    try:
+        for line in open('/proc/meminfo'):
+            if line.startswith('MemAvailable:'):
+                return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
+def test_config5_first_iterate_against_the_oracle():
+    """BASELINE config 5 at full size (Theta of order 34000) against the ORACLE, not only against properties: the first Gauss-Newton
+    iterate from the benchmark's seeded start, device (gpk_mg_potrf + gpk_mg_gn_step on one rank: the 1-GPU point of the scaling series)
+    vs O.gn_method (triangular formulation; reference src/PDEs.py:104-135) on the device's factor, <= 1e-6 relative -- the check bench.py
+    makes under `sharded_config.parity`, as a test (round 5).  The reference operation sequence (general LU solves) needs minutes at
+    this size and is left to the smaller configurations.  ~35 s of host BLAS and ~40 GB of host memory on the GPU box."""
+    import time
+    import gpk
+    from gpk.mg import MultiGpu
+    from src.sample_points import sampled_pts_rdm
+    Nd, Nb = 16000, 2000
+    N = 2 * Nd + Nb
+    need = 3.2 * 8.0 * N * N / 1e9 + 4.0 * 8.0 * N * (Nd + 1) / 1e9 + 8
+    if _host_mem_available_gb() < need:
+        pytest.skip(f'host memory available {_host_mem_available_gb():.0f} GB < {need:.0f} GB needed by the CPU oracle at order {N}')
+    ctx = gpk.Context(0)
+    np.random.seed(0)
+    Xd, Xb = sampled_pts_rdm(Nd, Nb, np.array([[0, 1], [0, 1]]))
+    z0 = np.random.normal(0.0, 1.0, Nd)
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    mgpu = MultiGpu(ctx, 0, 1, panel=512)
+    T = ctx.empty(N, N)
+    nugget = 1e-13
+    while True:
+        ctx.assemble('Nonlinear_elliptic', 'Gaussian', SIGMA, Xd, Xb, nugget, 'adaptive', out=T)
+        info = mgpu.potrf(T.ptr, N, T.ld)
+        if info == 0 or nugget > 1e-10:
+            break
+        nugget *= 10.0
+    assert info == 0
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0)
+    S, H, delta, _ = prob.workspace()
+    z = ctx.array(z0)
+    loss0, sinfo = mgpu.gn_step(prob.struct, z.ptr, 1.0, S.ptr, S.ld, None, H.ptr, H.ld, delta.ptr)
+    assert sinfo == 0
+    z1 = z.download()
+    loss1 = ctx.gn_loss(prob, z)
+    L = T.download()
+    for i0 in range(0, N, 2048):                                  # zero the strict upper triangle in place (no second 9.2 GB copy)
+        i1 = min(i0 + 2048, N)
+        L[i0:i1, i1:] = 0.0
+        L[i0:i1, i0:i1] = np.tril(L[i0:i1, i0:i1])
+    prob.release_workspace(); mgpu.close(); ctx.close()
+    t0 = time.perf_counter()
+    z1_o, hist = O.gn_method(O.EllipticSystem(1.0, 3.0, f, g), [L], z0, 1, 1)
+    dt = time.perf_counter() - t0
+    r = float(np.linalg.norm(z1 - z1_o) / np.linalg.norm(z1_o))
+    print(f'\n[c5] order {N}, nugget {nugget:g}: first iterate device vs oracle rel. dev {r:.2e}; loss(z0) device {loss0:.12e} oracle {hist[0]:.12e}; '
+          f'loss(z1) device {loss1:.12e} oracle {hist[1]:.12e}; oracle step {dt:.1f} s')
+    assert r <= 1e-6                                              # north star: within 1e-6 relative of the reference path
+    assert loss0 == pytest.approx(hist[0], rel=1e-6) and loss1 == pytest.approx(hist[1], rel=1e-5)
