@@ -16,8 +16,8 @@ The LAST stdout line is compact (bench_line.py, ~5 KB: contract fields, roofline
 secondary workload); the full result object goes to bench_detail.json and stderr.
 
 A "step" is one Gauss-Newton step of the reference's GN_method (src/PDEs.py:117-127): Hessian_GN + grad_loss + linear
-solve + update + one loss evaluation, executed as the product's default sequence gpk_gn_step (TRSM with n_z+1 right-hand sides +
-SYRK + Cholesky of H + triangular solve) followed by gpk_gn_loss of the new iterate, all operands resident in HBM.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
+solve + update + one loss evaluation, executed as ONE gpk_gn_step call (TRSM with n_z+1 right-hand sides + SYRK + Cholesky of H + triangular solve + update, and the loss of
+the iterate it starts from by true substitution on a side stream), all operands resident in HBM -- the product's default sequence.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
 Rank 0 prints ONE JSON line.  `roofline.achieved` is measured live with HIP events recorded inside the timed steps on
 the stream the kernels run on; `roofline.traffic` is read from the newest stored PMC pass under profiles/ and says so
 (`traffic_source`); `cpu_baseline` times the CPU oracle (reference operation sequence) on this box's host cores.
@@ -51,8 +51,8 @@ WORKLOADS = {
     'c3': (2000, 400, 8, 'Burgers1d anisotropic_Gaussian sigma=[0.3,0.05] N_domain=2000 N_boundary=400 (->399) nugget 1e-5 seed 0 (BASELINE config 3)'),
     'c4': (1600, 200, 8, 'DarcyFlow2d inverse problem Gaussian sigma=0.2 N_domain=1600 N_boundary=200 N_data=60 noise=1e-3 nugget 1e-8 seed 9999 (BASELINE config 4)'),
 }
-TIMED_SEQUENCE = {True: 'gpk_gn_step + gpk_gn_loss per step (the product default: src/PDEs.py _gn_iterate)',
-                  False: 'gpk_gn_step alone (GPK_INSTEP_LOSS=1: loss taken from the step)'}
+TIMED_SEQUENCE = {False: 'gpk_gn_step per step, exact in-step loss (the product default: src/PDEs.py _gn_iterate)',
+                  True: 'gpk_gn_step + gpk_gn_loss per step (GPK_SEPARATE_LOSS=1, the round-4 sequence)'}
 PARITY_TOL = 1e-6                 # north star: device iterate within 1e-6 relative of the reference path on the same points
 SIGMA, ALPHA, M_EXP = 0.2, 1.0, 3.0
 
@@ -338,9 +338,11 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     prob.workspace()
     dev_first = first_step_on_device(ctx, prob, z0)               # for `parity` (also the first, code-object-loading step)
     # A timed step is what the product's GN_method executes per iteration (nonlinpdes-gpsolver_amd/src/PDEs.py, _gn_iterate; the
-    # reference's src/PDEs.py:117-127): gpk_gn_step, then gpk_gn_loss of the new iterate (true substitution).  GPK_INSTEP_LOSS=1 -- the
-    # product's labelled variant that takes the loss gpk_gn_step returns for free -- drops the second call here as it does there.
-    with_loss = os.environ.get('GPK_INSTEP_LOSS', '0') != '1'
+    # reference's src/PDEs.py:117-127 = Hessian + gradient + solve + update + one loss evaluation): gpk_gn_step, which since round 5
+    # returns the loss of the iterate it starts from by true substitution (exact; computed on the chain stream next to the solve
+    # phase), so that one call IS one reference iteration.  GPK_SEPARATE_LOSS=1 -- in the product and here -- is round 4's sequence:
+    # gpk_gn_step followed by a gpk_gn_loss call of its own.
+    with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'
     losses = [ctx.gn_loss(prob, z)]
     loss_s = 0.0
 
@@ -734,7 +736,7 @@ def run_system(args, workload, steps=None, warmup=None):
     prob.workspace()
     dev_first = first_step_on_device(ctx, prob, z0)
     z = ctx.array(z0)
-    with_loss = os.environ.get('GPK_INSTEP_LOSS', '0') != '1'       # (as in run_single: the product's per-iteration sequence)
+    with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'       # (as in run_single: the product's per-iteration sequence)
     losses = [ctx.gn_loss(prob, z)]
     loss_s = 0.0
 
@@ -978,9 +980,9 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
         step_only = lambda: mgpu.gn_step(ps, z.data_ptr(), 1.0, S.data_ptr(), lds, S2.data_ptr(), Hb.data_ptr(), lds, delta.data_ptr())[0]
     else:
         step_only = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
-    # the timed step is the product's per-iteration sequence here too: the (collective) step, then the loss of the new iterate by true
-    # substitution with the factor every rank holds (replicated: one vector; src/PDEs.py:117-127 of the reference)
-    with_loss = os.environ.get('GPK_INSTEP_LOSS', '0') != '1'
+    # the timed step is the product's per-iteration sequence here too: the (collective) step, which reports the loss of the iterate it
+    # starts from by true substitution (replicated, on the chain stream); GPK_SEPARATE_LOSS=1 adds a loss call of its own per step
+    with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'
 
     def loss_of_iterate():
         w = torch.cat([ALPHA * z ** M_EXP - tf, z, tg])           # F(z), src/PDEs.py:84-85 of the reference

@@ -11,10 +11,9 @@
  *     symmetric outputs are stored full.  Vector loads are 16-byte wide when pointer and leading dimension allow
  *     (even ld, 16-byte aligned base); any alignment is accepted.
  *   - calls are asynchronous on the handle's stream; functions that return host scalars (info, loss, ratios)
- *     synchronise that stream.  One host thread per handle.  The product entry points of this header and of gpk_mg.h keep
- *     all mutable state in the handle; the only process-wide state of the library are the DEVELOPMENT switches of
- *     gpk_debug.h (gpk_debug_set: kernel-variant selection for A/B measurements and tests), which default to the tuned
- *     configuration, are never touched by the product path and must not be flipped while another thread is inside a call.
+ *     synchronise that stream.  One host thread per handle.  The library has NO process-wide mutable state (round 4): all
+ *     state, including the development / tuning switches (gpk_debug.h: gpk_tune(handle, key, value), never called by the
+ *     product path), lives in the handle, so handles of one process are independent of each other.
  *   - there is NO CPU fallback: without a gfx950 device gpk_create fails.
  */
 #ifndef GPK_H
@@ -186,7 +185,11 @@ int gpk_gn_worksize(const gpk_gn_problem* host_prob, int lds, int* host_lds, siz
  *   S  = [L^{-1}A(z) | L^{-1}F(z)]                (s_rows x (nz+1), ld lds)
  *   Hb = S^T S  (bordered: H/2, g/2, loss)        ((nz+1) x (nz+1), ld ldh)
  *   z <- z - step * H^{-1} g                       via Cholesky of Hb
- * host_loss_in = loss(z_in); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g. */
+ * host_loss_in = loss(z_in) = sum_k ||L_k^{-1} F_k(z_in)||^2 by TRUE SUBSTITUTION with the factor(s) (round 5: one vector, solved on the
+ * handle's chain stream while the solve phase of the step runs; exact to rounding like gpk_gn_loss -- rounds 2-4 returned the squared norm
+ * of the F column of the GEMM-only solve instead, ~1e-8 relative error at nugget <= 1e-12 near convergence; the structured modes below
+ * report their own form of it); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g.  One call = one iteration of the
+ * reference's GN_method loop (Hessian, gradient, solve, update, one loss evaluation). */
 int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double step_size,
                 double* S, int lds, double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);
 /* OPTIONAL structured solve of the elliptic system (not what the reference does per step; off unless W1/W2/v0 are set).  A(z) =

@@ -176,13 +176,13 @@ class _GPEquation(object):
                     print('iter = 0', 'Loss =', value)
                 else:
                     print('iter = ', it, 'Gauss-Newton step size =', step_size, ' Loss = ', value)
-        # The loss history is the reference's: J(z_0), then J(z_k) after every update (src/PDEs.py:108-124).  Every value comes from
-        # gpk_gn_loss -- true substitution with the factor, exact to rounding -- since round 4.  gpk_gn_step also returns the loss of the
-        # iterate it starts from, for free, as the squared norm of the F column of its GEMM-only solve; through the explicit inverses of
-        # the diagonal blocks that number carries ~1e-8 relative error at nugget <= 1e-12 near convergence (DESIGN.md section 4
-        # "Numerics"), which is not what a user comparing digits with the reference expects.  GPK_INSTEP_LOSS=1 takes the free numbers
-        # again (one triangular solve with one vector less per step: 3-5 % of a step at BASELINE config 2).
-        if os.environ.get('GPK_INSTEP_LOSS', '0') == '1':
+        # The loss history is the reference's: J(z_0), then J(z_k) after every update (src/PDEs.py:108-124).  gpk_gn_step returns the
+        # loss of the iterate it STARTS from -- since round 5 by true substitution with the factor (one vector, solved on the chain
+        # stream of the step's pipeline while the solve phase runs: exact to rounding, like gpk_gn_loss) -- so max_iter steps yield
+        # J(z_0) .. J(z_{max_iter-1}) and one gpk_gn_loss closes the history.  Rounds 2-4 took that number from the F column of the
+        # GEMM-only solve (~1e-8 relative error at nugget <= 1e-12 near convergence: gpk_tune(52, 0)) and round 4 therefore called
+        # gpk_gn_loss after every step; GPK_SEPARATE_LOSS=1 keeps that sequence (same numbers to rounding, one more solve per step).
+        if os.environ.get('GPK_SEPARATE_LOSS', '0') != '1':
             for it in range(max_iter):
                 loss_in, _info = ctx.gn_step(prob, z, step_size)  # loss of the iterate the step starts from
                 record(it, loss_in)

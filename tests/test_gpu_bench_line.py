@@ -40,7 +40,7 @@ def test_default_command_of_the_driver_prints_a_compact_parseable_line():
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config'):
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 20 and d['warmup'] == 5 and d['value_workload'] == 'c2' and d['dtype'] == 'f64'
-    assert 'N_domain=4000' in d['config']['workload'] and 'gpk_gn_step + gpk_gn_loss' in d['config']['timed_sequence']
+    assert 'N_domain=4000' in d['config']['workload'] and 'exact in-step loss' in d['config']['timed_sequence']
     assert abs(d['value'] * d['ms_per_step'] / 1e3 - 1.0) < 1e-4
     r, c, par = d['roofline'], d['cpu_baseline'], d['parity']
     assert r['bound'] == 'mfma' and r['peak'] == 78.6 and 0.3 < r['frac'] < 1 and r['phase_ms'] < d['ms_per_step'] and len(r['kernel']) <= 80

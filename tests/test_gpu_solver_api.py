@@ -202,9 +202,13 @@ def test_error_metrics_on_device_match_the_reference_definitions():
 
 
 def test_class_api_loss_history_is_exact(monkeypatch):
-    """Round 4: the loss history of GN_method comes from gpk_gn_loss (true substitution) for every entry -- at nugget 1e-12 the free
-    in-step value of gpk_gn_step (explicit diagonal-block inverses) is only good to ~1e-8 near convergence.  Checked against the oracle's
-    loss of the final iterate on the device's own factor; GPK_INSTEP_LOSS=1 restores the cheaper history, same iterates."""
+    """The loss history of GN_method is exact to rounding in EVERY entry.  Round 4 got there by calling gpk_gn_loss (true substitution) after
+    every step, because the free in-step value of gpk_gn_step (F column of the GEMM-only solve, explicit diagonal-block inverses) is only good
+    to ~1e-8 near convergence at nugget 1e-12; since round 5 gpk_gn_step itself reports the loss by true substitution (on the chain stream,
+    next to the solve phase), so the default loop is one call per iteration.  Checked against the oracle's loss on the device's own factor for
+    every iterate of the history; GPK_SEPARATE_LOSS=1 (round 4's sequence) gives the same iterates and the same numbers; gpk_tune(52, 0)
+    restores the approximate in-step number (same iterates, losses within 1e-5)."""
+    import gpk
     from oracle import gp_oracle as O
     from src.PDEs import Nonlinear_elliptic2d
 
@@ -224,8 +228,24 @@ def test_class_api_loss_history_is_exact(monkeypatch):
     want_first = O.loss(sysm, [e.L], e.init_sol)
     assert e.loss_hist[-1] == pytest.approx(want_last, rel=1e-9)
     assert e.loss_hist[0] == pytest.approx(want_first, rel=1e-12)
-    monkeypatch.setenv('GPK_INSTEP_LOSS', '1')
+    monkeypatch.setenv('GPK_SEPARATE_LOSS', '1')
     f = run()
-    np.testing.assert_array_equal(f.sol_sampled_pts, e.sol_sampled_pts)       # same steps, only the reported numbers differ
-    np.testing.assert_allclose(f.loss_hist, e.loss_hist, rtol=1e-5)
+    np.testing.assert_array_equal(f.sol_sampled_pts, e.sol_sampled_pts)       # same steps, only the way the numbers are obtained differs
+    np.testing.assert_allclose(f.loss_hist, e.loss_hist, rtol=1e-9)            # both by true substitution (different launch shapes: not bitwise)
     assert f.loss_hist[-1] == e.loss_hist[-1]                                # the closing value always came from gpk_gn_loss
+    monkeypatch.delenv('GPK_SEPARATE_LOSS')
+    try:
+        gpk.load_library().gpk_debug_set(52, 0)                               # the approximate number of rounds 2-4
+        a = run()
+    finally:
+        gpk.load_library().gpk_debug_set(52, 1)
+    np.testing.assert_array_equal(a.sol_sampled_pts, e.sol_sampled_pts)
+    np.testing.assert_allclose(a.loss_hist, e.loss_hist, rtol=1e-5)
+    # and the overlap itself is only a schedule: issued on the main stream (52 = 2) the numbers are bit-identical
+    try:
+        gpk.load_library().gpk_debug_set(52, 2)
+        b = run()
+    finally:
+        gpk.load_library().gpk_debug_set(52, 1)
+    np.testing.assert_array_equal(b.loss_hist, e.loss_hist)
+    np.testing.assert_array_equal(b.sol_sampled_pts, e.sol_sampled_pts)
