@@ -17,7 +17,7 @@ secondary workload); the full result object goes to bench_detail.json and stderr
 
 A "step" is one Gauss-Newton step of the reference's GN_method (src/PDEs.py:117-127): Hessian_GN + grad_loss + linear
 solve + update + one loss evaluation, executed as ONE gpk_gn_step call (TRSM with n_z+1 right-hand sides + SYRK + Cholesky of H + triangular solve + update, and the loss of
-the iterate it starts from by true substitution on a side stream), all operands resident in HBM -- the product's default sequence.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
+the iterate it starts from by true substitution), all operands resident in HBM -- the product's default sequence.  Nothing is cached across steps (the dense "F1" formulation of SURVEY 8d).
 Rank 0 prints ONE JSON line.  `roofline.achieved` is measured live with HIP events recorded inside the timed steps on
 the stream the kernels run on; `roofline.traffic` is read from the newest stored PMC pass under profiles/ and says so
 (`traffic_source`); `cpu_baseline` times the CPU oracle (reference operation sequence) on this box's host cores.
@@ -339,8 +339,8 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     dev_first = first_step_on_device(ctx, prob, z0)               # for `parity` (also the first, code-object-loading step)
     # A timed step is what the product's GN_method executes per iteration (nonlinpdes-gpsolver_amd/src/PDEs.py, _gn_iterate; the
     # reference's src/PDEs.py:117-127 = Hessian + gradient + solve + update + one loss evaluation): gpk_gn_step, which since round 5
-    # returns the loss of the iterate it starts from by true substitution (exact; computed on the chain stream next to the solve
-    # phase), so that one call IS one reference iteration.  GPK_SEPARATE_LOSS=1 -- in the product and here -- is round 4's sequence:
+    # returns the loss of the iterate it starts from by true substitution (exact; one vector solved in front of the solve phase),
+    # so that one call IS one reference iteration.  GPK_SEPARATE_LOSS=1 -- in the product and here -- is round 4's sequence:
     # gpk_gn_step followed by a gpk_gn_loss call of its own.
     with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'
     losses = [ctx.gn_loss(prob, z)]
@@ -981,7 +981,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
     else:
         step_only = lambda: solver.gn_step(ps, nz, N, Theta, z, S, Hb, delta, 1.0, rev=True, Dinv=Dinv, S2=S2)[0]
     # the timed step is the product's per-iteration sequence here too: the (collective) step, which reports the loss of the iterate it
-    # starts from by true substitution (replicated, on the chain stream); GPK_SEPARATE_LOSS=1 adds a loss call of its own per step
+    # starts from by true substitution (replicated: one vector); GPK_SEPARATE_LOSS=1 adds a loss call of its own per step
     with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'
 
     def loss_of_iterate():

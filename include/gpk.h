@@ -185,8 +185,8 @@ int gpk_gn_worksize(const gpk_gn_problem* host_prob, int lds, int* host_lds, siz
  *   S  = [L^{-1}A(z) | L^{-1}F(z)]                (s_rows x (nz+1), ld lds)
  *   Hb = S^T S  (bordered: H/2, g/2, loss)        ((nz+1) x (nz+1), ld ldh)
  *   z <- z - step * H^{-1} g                       via Cholesky of Hb
- * host_loss_in = loss(z_in) = sum_k ||L_k^{-1} F_k(z_in)||^2 by TRUE SUBSTITUTION with the factor(s) (round 5: one vector, solved on the
- * handle's chain stream while the solve phase of the step runs; exact to rounding like gpk_gn_loss -- rounds 2-4 returned the squared norm
+ * host_loss_in = loss(z_in) = sum_k ||L_k^{-1} F_k(z_in)||^2 by TRUE SUBSTITUTION with the factor(s) (round 5: one vector, solved in front
+ * of the solve phase; exact to rounding like gpk_gn_loss -- rounds 2-4 returned the squared norm
  * of the F column of the GEMM-only solve instead, ~1e-8 relative error at nugget <= 1e-12 near convergence; the structured modes below
  * report their own form of it); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g.  One call = one iteration of the
  * reference's GN_method loop (Hessian, gradient, solve, update, one loss evaluation). */

@@ -104,10 +104,11 @@ struct GpkTune {
     int force_cfg = 0;                  // key 0: development aid (): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
     int use_dinv = 1;                   // key 10: 0 = substitution strips even when the inverses are supplied
     int eikonal_lz = 1;                 // key 23: 0 = dense schedule for the Eikonal, Burgers and Darcy systems; 2 = leading-zero layout with the conservative closed-form staircase for Eikonal (round 2-3) instead of the exact two-segment profile
-    int exact_loss = 1;                 // key 52: gpk_gn_step reports the loss of the iterate it starts from by TRUE SUBSTITUTION (round 5): F(z) solved with the factor(s) as a
-                                        // single vector on the chain stream of the pipeline while the solve phase runs on the main stream (the chain partition idles there),
-                                        // instead of the squared norm of the F column of the GEMM-only solve (~1e-8 relative error at nugget <= 1e-12 near convergence).
-                                        // 0 = the free, approximate number (rounds 2-4).  2 = exact, but issued on the main stream in front of the solve (no overlap: the A/B of the overlap)
+    int exact_loss = 1;                 // key 52: 1 = gpk_gn_step reports the loss of the iterate it starts from by TRUE SUBSTITUTION (round 5): F(z) solved with the factor(s) as a
+                                        // single vector in front of the solve phase (what gpk_gn_loss does; +0.43 ms at config 2), instead of 0 = the squared norm of the F column of the
+                                        // GEMM-only solve (free, but ~1e-8 relative error at nugget <= 1e-12 near convergence; rounds 2-4).  Overlapping that chain with the solve phase was
+                                        // measured and lost: on the 32-CU chain partition next to whole-chip GEMM launches the solve phase grows by 0.67 ms; with the first launches of the
+                                        // solve moved to the 224-CU partition meanwhile by 0.63 ms (the chain alone takes 0.93 ms on 32 CUs: four chain workgroups per CU share one memory queue)
     int structured = 1;                 // key 40: 0 = ignore W1/W2/v0 (always the triangular solve); 1 = honour W1/W2/v0 only (never the Gram blocks); 2 would be redundant: the Gram level is used whenever G/pvec are set
 };
 
@@ -123,14 +124,8 @@ struct gpk_ctx {
     int trsv_epoch = 0;
     void* d_trsv_gran = nullptr;    // {value, epoch} granules of the fused triangular solve with data-tagged hand-offs (64 per block), allocated on first use
     long long trsv_gran_epoch = 0;
-    // a second set for single-vector solves issued on a SECONDARY stream while the main stream may run one of its own (the exact
-    // in-step loss of gpk_gn_step on the chain stream): selected by trsv_alt around those calls
-    void* d_trsv_gran2 = nullptr;
-    long long trsv_gran2_epoch = 0;
-    int trsv_alt = 0;
     double* d_loss_work = nullptr;  // F(z) as one contiguous vector for the exact in-step loss (rows doubles, grown on demand)
     size_t loss_work_cap = 0;       // doubles
-    hipEvent_t ev_loss[2] = {nullptr, nullptr};   // main stream -> chain stream (z is ready), chain stream -> main stream (the loss is there)
     int* d_obflags = nullptr;       // 64 flags of the persistent outer-block Cholesky kernel (epoch-tagged)
     int ob_epoch = 0;
     unsigned panel_loaded = 0;      // running total of "diagonal block loaded" tickets issued to the Cholesky panel kernel (d_flags[GPK_MAX_TRSV_BLOCKS])
@@ -232,7 +227,7 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 int gpk_i_ensure_points(gpk_handle h, size_t doubles);
 // pieces of the Gauss-Newton step used by the multi-GPU schedule (gpk_gn.hip)
 int gpk_i_gn_dims(gpk_handle h, const gpk_gn_problem* p, int* nz, int* rows);
-int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double** d_out, void** ev);   // gpk_tune key 52
+int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double** d_out);   // gpk_tune key 52: loss(z) by substitution on h->stream
 int gpk_i_gn_finish(gpk_handle h, const gpk_gn_problem* p, int nz, int rev, const double* Hb, int ldh, double* scratch, double* delta,
                     double* z, double step_size);
 

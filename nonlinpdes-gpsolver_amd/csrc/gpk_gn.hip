@@ -230,26 +230,14 @@ int substitution_loss(gpk_handle h, const gpk_gn_problem* p, const Dims& d, cons
     return gpk_i_dot(h, work, work, d.rows, d_out);
 }
 
-// The same, issued on the CHAIN stream of the pipeline (a 32-CU partition that idles during the solve phase of the step) so that it runs
-// next to the solve-phase GEMMs of the main stream; the caller makes the main stream wait for ev_loss[1] before it reads d_scalars[8].
-// overlap == false (no chain stream, or gpk_tune(52, 2)): on the main stream, in front of the solve.
-int exact_loss_begin(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z, bool overlap) {
+// the exact in-step loss of gpk_gn_step / gpk_mg_gn_step (gpk_tune key 52): the same on the handle's own scratch vector, -> d_scalars[8]
+int exact_loss(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z) {
     if (h->loss_work_cap < (size_t)d.rows) {
-        if (h->d_loss_work) { GPK_HIP(h, hipStreamSynchronize(h->stream)); if (h->pipe_c) GPK_HIP(h, hipStreamSynchronize(h->pipe_c)); (void)hipFree(h->d_loss_work); h->d_loss_work = nullptr; h->loss_work_cap = 0; }
+        if (h->d_loss_work) { GPK_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_loss_work); h->d_loss_work = nullptr; h->loss_work_cap = 0; }
         GPK_HIP(h, hipMalloc((void**)&h->d_loss_work, (size_t)d.rows * sizeof(double)));
         h->loss_work_cap = (size_t)d.rows;
     }
-    if (!overlap) return substitution_loss(h, p, d, z, h->d_loss_work, h->d_scalars + 8);
-    for (int i = 0; i < 2; ++i) if (!h->ev_loss[i]) GPK_HIP(h, hipEventCreateWithFlags(&h->ev_loss[i], hipEventDisableTiming));
-    const hipStream_t main_s = h->stream;
-    GPK_HIP(h, hipEventRecord(h->ev_loss[0], main_s));               // z (and whatever the caller queued before the step) is ready
-    GPK_HIP(h, hipStreamWaitEvent(h->pipe_c, h->ev_loss[0], 0));
-    h->stream = h->pipe_c; h->trsv_alt = 1;
-    const int rc = substitution_loss(h, p, d, z, h->d_loss_work, h->d_scalars + 8);
-    h->stream = main_s; h->trsv_alt = 0;
-    if (rc) { (void)hipStreamSynchronize(h->pipe_c); return rc; }
-    GPK_HIP(h, hipEventRecord(h->ev_loss[1], h->pipe_c));
-    return 0;
+    return substitution_loss(h, p, d, z, h->d_loss_work, h->d_scalars + 8);
 }
 
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) { (h)->prof_phase = (i); GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } } while (0)
@@ -550,7 +538,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     const bool gram = h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
     double* d_loss = h->d_scalars;
-    bool exact = false, exact_overlap = false;                       // (d_scalars[8]: the loss by substitution, exact_loss_begin)
+    bool exact = false;                                              // (d_scalars[8]: the loss by substitution, exact_loss)
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     if ((gram || (h->tune.structured && p->W1)) && (long)d.rows * lds < 5L * nz + d.rows)
         return gpk_bad_arg(h, "gn: S too small for the scratch vectors of the structured modes");
@@ -580,12 +568,8 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         GPK_LAUNCH_CHECK(h);
         GPK_PROF_MARK(h, 1);
     } else {
-        // the loss of the iterate this step starts from, exact (true substitution): on the chain stream, next to the solve phase
-        if (h->tune.exact_loss) {
-            exact_overlap = h->tune.exact_loss == 1 && h->pipe_c && !h->pipe_unavailable;
-            GPK_TRY(exact_loss_begin(h, p, d, z, exact_overlap));
-            exact = true;
-        }
+        // the loss of the iterate this step starts from, exact (true substitution with the factors, one vector), in front of the solve
+        if (h->tune.exact_loss) { GPK_TRY(exact_loss(h, p, d, z)); exact = true; }
         GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     }
     // Hb = W^T W and its Cholesky factor, pipelined by column blocks (gpk_factor.hip); d_loss = Hb[nz][nz] before factoring;
@@ -633,7 +617,6 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     int info = 0;
     double loss = 0.0;
     GPK_HIP(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (exact_overlap) GPK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_loss[1], 0));
     GPK_HIP(h, hipMemcpyAsync(&loss, exact ? h->d_scalars + 8 : d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
     if (h->prof) {
@@ -714,15 +697,12 @@ extern "C" int gpk_gn_measurement(gpk_handle h, const gpk_gn_problem* p, const d
 }
 
 // ---- building blocks of the multi-GPU step (gpk_mg.hip) ---------------------------------------------------------------------
-// exact in-step loss for the sharded step (replicated on every rank: one vector): begin at the start of the step, the device scalar and the
-// event the main stream must wait for before reading it come back (ev == nullptr: it was issued on the main stream itself)
-int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double** d_out, void** ev) {
+// exact in-step loss for the sharded step (replicated on every rank: one vector), on h->stream; the device scalar comes back
+int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double** d_out) {
     Dims d;
     GPK_TRY(check_prob(h, p, d));
-    const bool overlap = h->tune.exact_loss == 1 && h->pipe_c && !h->pipe_unavailable;
-    GPK_TRY(exact_loss_begin(h, p, d, z, overlap));
+    GPK_TRY(exact_loss(h, p, d, z));
     *d_out = h->d_scalars + 8;
-    *ev = overlap ? (void*)h->ev_loss[1] : nullptr;
     return 0;
 }
 

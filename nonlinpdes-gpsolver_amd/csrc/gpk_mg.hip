@@ -540,11 +540,9 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     if (lds < nc || ldh < nc) return gpk_bad_arg(h, "gpk_mg_gn_step: lds/ldh < nz+1");
     const int db = p->dinv_block > 0 ? p->dinv_block : 256;
     const hipStream_t s = h->stream;
-    // ---- the loss of the iterate the step starts from, by true substitution (replicated; on the chain stream of the handle, next to
-    //      the solve of my column shard -- as in gpk_gn_step, gpk_tune key 52)
+    // ---- the loss of the iterate the step starts from, by true substitution (replicated: one vector; as in gpk_gn_step, gpk_tune key 52)
     double* d_exact = nullptr;
-    void* ev_exact = nullptr;
-    if (h->tune.exact_loss) GPK_TRY(gpk_i_gn_exact_loss(h, p, z, &d_exact, &ev_exact));
+    if (h->tune.exact_loss) GPK_TRY(gpk_i_gn_exact_loss(h, p, z, &d_exact));
     // ---- S <- [A | F] in the leading-zero layout on every rank (a memset + O(N)); my column shard of L^{-1}[A | F] -> S2
     GPK_TRY(gpk_gn_build_rev(h, p, z, S, lds));
     column_bounds(nc, nz, rows, P, mg->col_align, mg->bounds);
@@ -645,7 +643,6 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     GPK_TRY(gpk_i_gn_finish(h, p, nz, 1, Hb, ldh, S, delta, z, step_size));
     double loss = 0.0;
     int info = 0;
-    if (ev_exact) GPK_HIP(h, hipStreamWaitEvent(s, (hipEvent_t)ev_exact, 0));
     GPK_HIP(h, hipMemcpyAsync(&loss, d_exact ? d_exact : d_loss, sizeof(double), hipMemcpyDeviceToHost, s));
     if (mg->shard_hb) GPK_TRY(gather_info(mg, &info));
     else {

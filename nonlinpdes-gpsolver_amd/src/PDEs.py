@@ -177,8 +177,8 @@ class _GPEquation(object):
                 else:
                     print('iter = ', it, 'Gauss-Newton step size =', step_size, ' Loss = ', value)
         # The loss history is the reference's: J(z_0), then J(z_k) after every update (src/PDEs.py:108-124).  gpk_gn_step returns the
-        # loss of the iterate it STARTS from -- since round 5 by true substitution with the factor (one vector, solved on the chain
-        # stream of the step's pipeline while the solve phase runs: exact to rounding, like gpk_gn_loss) -- so max_iter steps yield
+        # loss of the iterate it STARTS from -- since round 5 by true substitution with the factor (one vector, solved in front of the
+        # solve phase: exact to rounding, like gpk_gn_loss) -- so max_iter steps yield
         # J(z_0) .. J(z_{max_iter-1}) and one gpk_gn_loss closes the history.  Rounds 2-4 took that number from the F column of the
         # GEMM-only solve (~1e-8 relative error at nugget <= 1e-12 near convergence: gpk_tune(52, 0)) and round 4 therefore called
         # gpk_gn_loss after every step; GPK_SEPARATE_LOSS=1 keeps that sequence (same numbers to rounding, one more solve per step).
