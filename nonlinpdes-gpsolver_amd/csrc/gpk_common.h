@@ -104,11 +104,13 @@ struct GpkTune {
     int force_cfg = 0;                  // key 0: development aid (): 0 auto, 1 = 128x128 tiles, 2 = 64x64 tiles
     int use_dinv = 1;                   // key 10: 0 = substitution strips even when the inverses are supplied
     int eikonal_lz = 1;                 // key 23: 0 = dense schedule for the Eikonal, Burgers and Darcy systems; 2 = leading-zero layout with the conservative closed-form staircase for Eikonal (round 2-3) instead of the exact two-segment profile
-    int exact_loss = 1;                 // key 52: 1 = gpk_gn_step reports the loss of the iterate it starts from by TRUE SUBSTITUTION (round 5): F(z) solved with the factor(s) as a
-                                        // single vector in front of the solve phase (what gpk_gn_loss does; +0.43 ms at config 2), instead of 0 = the squared norm of the F column of the
-                                        // GEMM-only solve (free, but ~1e-8 relative error at nugget <= 1e-12 near convergence; rounds 2-4).  Overlapping that chain with the solve phase was
-                                        // measured and lost: on the 32-CU chain partition next to whole-chip GEMM launches the solve phase grows by 0.67 ms; with the first launches of the
-                                        // solve moved to the 224-CU partition meanwhile by 0.63 ms (the chain alone takes 0.93 ms on 32 CUs: four chain workgroups per CU share one memory queue)
+    int exact_loss = 1;                 // key 52: 1 = gpk_gn_step reports the loss of the iterate it starts from by TRUE SUBSTITUTION (round 5): F(z) is written at the start of the
+                                        // step and solved with the factor(s) as a single vector on the GEMM partition's stream next to the END of the step (last panel chain of the
+                                        // pipelined phase on the other partition, then the backward solve of the tail on the main stream -- latency chains on an idle chip);
+                                        // 2 = the same chain on the main stream in front of the solve phase (+0.43 ms at config 2, what a gpk_gn_loss call costs);
+                                        // 0 = the squared norm of the F column of the GEMM-only solve (free, ~1e-8 relative error at nugget <= 1e-12 near convergence; rounds 2-4).
+                                        // Measured and lost: the chain next to the SOLVE phase -- on the 32-CU chain partition beside whole-chip GEMM launches the solve grows by
+                                        // 0.67 ms, with the first solve launches moved to the 224-CU partition meanwhile by 0.63 ms (the chain alone takes 0.93 ms on 32 CUs)
     int structured = 1;                 // key 40: 0 = ignore W1/W2/v0 (always the triangular solve); 1 = honour W1/W2/v0 only (never the Gram blocks); 2 would be redundant: the Gram level is used whenever G/pvec are set
 };
 
@@ -126,6 +128,14 @@ struct gpk_ctx {
     long long trsv_gran_epoch = 0;
     double* d_loss_work = nullptr;  // F(z) as one contiguous vector for the exact in-step loss (rows doubles, grown on demand)
     size_t loss_work_cap = 0;       // doubles
+    // the exact in-step loss runs its chain on the GEMM partition's stream NEXT TO the end of the step (the last panel chain of the pipelined
+    // phase on the chain partition -- disjoint CUs -- and the backward single-vector solve of the tail on the main stream: latency chains on an
+    // otherwise idle chip): a second granule set for that concurrent solve, and the events main -> side (F(z) is built; side may start) and
+    // side -> main (the scalar is there)
+    void* d_trsv_gran2 = nullptr;
+    long long trsv_gran2_epoch = 0;
+    int trsv_alt = 0;
+    hipEvent_t ev_loss[2] = {nullptr, nullptr};
     int* d_obflags = nullptr;       // 64 flags of the persistent outer-block Cholesky kernel (epoch-tagged)
     int ob_epoch = 0;
     unsigned panel_loaded = 0;      // running total of "diagonal block loaded" tickets issued to the Cholesky panel kernel (d_flags[GPK_MAX_TRSV_BLOCKS])

@@ -60,6 +60,8 @@ extern "C" int gpk_destroy(gpk_handle h) {
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_trsv_gran) (void)hipFree(h->d_trsv_gran);
     if (h->d_loss_work) (void)hipFree(h->d_loss_work);
+    if (h->d_trsv_gran2) (void)hipFree(h->d_trsv_gran2);
+    for (int i = 0; i < 2; ++i) if (h->ev_loss[i]) (void)hipEventDestroy(h->ev_loss[i]);
     if (h->d_obflags) (void)hipFree(h->d_obflags);
     if (h->d_pts) (void)hipFree(h->d_pts);
     if (h->d_work) (void)hipFree(h->d_work);

@@ -1615,11 +1615,14 @@ int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double
     if (n <= 0) return 0;
     const int nblk = gpk_ceil_div(n, NB);
     if (h->tune.fused_trsv == 1 && nblk <= GPK_MAX_TRSV_BLOCKS) {     // data-tagged hand-offs (default)
-        if (!h->d_trsv_gran) GPK_HIP(h, hipMalloc(&h->d_trsv_gran, (size_t)GPK_MAX_TRSV_BLOCKS * NB * sizeof(TrsvGran)));
-        if (h->trsv_gran_epoch == 0) GPK_HIP(h, hipMemsetAsync(h->d_trsv_gran, 0, (size_t)GPK_MAX_TRSV_BLOCKS * NB * sizeof(TrsvGran), h->stream));
-        const long long ep = ++h->trsv_gran_epoch;
-        if (trans) trsv_gran_kernel<true><<<nblk, 256, 0, h->stream>>>(L, ldl, n, x, (TrsvGran*)h->d_trsv_gran, ep);
-        else       trsv_gran_kernel<false><<<nblk, 256, 0, h->stream>>>(L, ldl, n, x, (TrsvGran*)h->d_trsv_gran, ep);
+        // (trsv_alt: a solve issued on a secondary stream NEXT TO one of the main stream takes the second granule set)
+        void*& gran = h->trsv_alt ? h->d_trsv_gran2 : h->d_trsv_gran;
+        long long& gep = h->trsv_alt ? h->trsv_gran2_epoch : h->trsv_gran_epoch;
+        if (!gran) GPK_HIP(h, hipMalloc(&gran, (size_t)GPK_MAX_TRSV_BLOCKS * NB * sizeof(TrsvGran)));
+        if (gep == 0) GPK_HIP(h, hipMemsetAsync(gran, 0, (size_t)GPK_MAX_TRSV_BLOCKS * NB * sizeof(TrsvGran), h->stream));
+        const long long ep = ++gep;
+        if (trans) trsv_gran_kernel<true><<<nblk, 256, 0, h->stream>>>(L, ldl, n, x, (TrsvGran*)gran, ep);
+        else       trsv_gran_kernel<false><<<nblk, 256, 0, h->stream>>>(L, ldl, n, x, (TrsvGran*)gran, ep);
         GPK_LAUNCH_CHECK(h);
         return 0;
     }

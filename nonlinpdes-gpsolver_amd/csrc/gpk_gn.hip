@@ -231,13 +231,51 @@ int substitution_loss(gpk_handle h, const gpk_gn_problem* p, const Dims& d, cons
 }
 
 // the exact in-step loss of gpk_gn_step / gpk_mg_gn_step (gpk_tune key 52): the same on the handle's own scratch vector, -> d_scalars[8]
-int exact_loss(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z) {
-    if (h->loss_work_cap < (size_t)d.rows) {
-        if (h->d_loss_work) { GPK_HIP(h, hipStreamSynchronize(h->stream)); (void)hipFree(h->d_loss_work); h->d_loss_work = nullptr; h->loss_work_cap = 0; }
-        GPK_HIP(h, hipMalloc((void**)&h->d_loss_work, (size_t)d.rows * sizeof(double)));
-        h->loss_work_cap = (size_t)d.rows;
+int loss_work_reserve(gpk_handle h, const Dims& d) {
+    if (h->loss_work_cap >= (size_t)d.rows) return 0;
+    if (h->d_loss_work) {
+        GPK_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->pipe_g) GPK_HIP(h, hipStreamSynchronize(h->pipe_g));
+        (void)hipFree(h->d_loss_work); h->d_loss_work = nullptr; h->loss_work_cap = 0;
     }
+    GPK_HIP(h, hipMalloc((void**)&h->d_loss_work, (size_t)d.rows * sizeof(double)));
+    h->loss_work_cap = (size_t)d.rows;
+    return 0;
+}
+
+int exact_loss(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z) {
+    GPK_TRY(loss_work_reserve(h, d));
     return substitution_loss(h, p, d, z, h->d_loss_work, h->d_scalars + 8);
+}
+
+// The same in two halves (gpk_tune key 52 = 1): F(z) is written at the START of the step on the main stream (z is overwritten at its end);
+// the chain -- one single-vector solve per factor, then the dot product -- is issued LATE, on the GEMM partition's stream: behind that
+// stream's last product of the pipelined phase, or (after_main != 0: no pipelined phase) behind an event of the main stream, so that it
+// runs next to the last panel chain (other partition) and the backward solve of the tail (main stream), not next to GEMM launches.
+int exact_loss_build(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const double* z) {
+    GPK_TRY(loss_work_reserve(h, d));
+    for (int i = 0; i < 2; ++i) if (!h->ev_loss[i]) GPK_HIP(h, hipEventCreateWithFlags(&h->ev_loss[i], hipEventDisableTiming));
+    GPK_HIP(h, hipMemsetAsync(h->d_loss_work, 0, (size_t)d.rows * sizeof(double), h->stream));
+    GPK_TRY(build(h, p, z, h->d_loss_work, 1, 0, 0));
+    GPK_HIP(h, hipEventRecord(h->ev_loss[0], h->stream));            // F(z) is written
+    return 0;
+}
+
+// after_main: the phase before the tail ran on the main stream (no two-partition pipeline): the chain waits for it; otherwise it only waits
+// for F(z) and queues behind the GEMM partition's own last launch of the pipelined phase
+int exact_loss_chain(gpk_handle h, const Dims& d, bool after_main) {
+    const hipStream_t main_s = h->stream, side = h->pipe_g;
+    if (after_main) GPK_HIP(h, hipEventRecord(h->ev_loss[0], main_s));
+    GPK_HIP(h, hipStreamWaitEvent(side, h->ev_loss[0], 0));
+    h->stream = side; h->trsv_alt = 1;
+    int rc = 0;
+    for (int k = 0; k < d.ngroups && rc == 0; ++k)
+        if (d.g[k].L) rc = gpk_i_trsv(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, h->d_loss_work + d.g[k].off);
+    if (rc == 0) rc = gpk_i_dot(h, h->d_loss_work, h->d_loss_work, d.rows, h->d_scalars + 8);
+    h->stream = main_s; h->trsv_alt = 0;
+    if (rc) { (void)hipStreamSynchronize(side); return rc; }
+    GPK_HIP(h, hipEventRecord(h->ev_loss[1], side));
+    return 0;
 }
 
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) { (h)->prof_phase = (i); GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } } while (0)
@@ -538,7 +576,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     const bool gram = h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
     double* d_loss = h->d_scalars;
-    bool exact = false;                                              // (d_scalars[8]: the loss by substitution, exact_loss)
+    bool exact = false, exact_late = false;                          // (d_scalars[8]: the loss by substitution, exact_loss*)
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     if ((gram || (h->tune.structured && p->W1)) && (long)d.rows * lds < 5L * nz + d.rows)
         return gpk_bad_arg(h, "gn: S too small for the scratch vectors of the structured modes");
@@ -569,7 +607,12 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         GPK_PROF_MARK(h, 1);
     } else {
         // the loss of the iterate this step starts from, exact (true substitution with the factors, one vector), in front of the solve
-        if (h->tune.exact_loss) { GPK_TRY(exact_loss(h, p, d, z)); exact = true; }
+        if (h->tune.exact_loss) {
+            exact = true;
+            exact_late = h->tune.exact_loss == 1 && h->pipe_g && !h->pipe_unavailable;
+            if (exact_late) GPK_TRY(exact_loss_build(h, p, d, z));
+            else GPK_TRY(exact_loss(h, p, d, z));
+        }
         GPK_TRY(assemble_normal_equations(h, p, d, z, S, lds, Hb, ldh, 1.0, rev, &W));
     }
     // Hb = W^T W and its Cholesky factor, pipelined by column blocks (gpk_factor.hip); d_loss = Hb[nz][nz] before factoring;
@@ -603,6 +646,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     } else if (!gram) GPK_TRY(gpk_i_syrk_potrf(h, W, lds, d.rows, nz + 1, rev ? nz : 0, Hb, ldh, d_loss));
     GPK_PROF_MARK(h, 2);
     GPK_PROF_MARK(h, 3);
+    // the chain of the exact loss: on the GEMM partition's stream from here on (pipelined phase: that stream's last product finished before the
+    // last panel chain did, so it starts early; otherwise behind the factorisation just issued), next to the tail below
+    if (exact_late) GPK_TRY(exact_loss_chain(h, d, !h->prof_pipelined));
     double* dl = rev ? S : delta;                                    // scratch for the (reversed-order) solution: S is free now
     GPK_HIP(h, hipMemcpyAsync(dl, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, dl));
@@ -617,6 +663,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     int info = 0;
     double loss = 0.0;
     GPK_HIP(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (exact_late) GPK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_loss[1], 0));
     GPK_HIP(h, hipMemcpyAsync(&loss, exact ? h->d_scalars + 8 : d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
     if (h->prof) {

@@ -17,8 +17,8 @@ T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-13, 'adapt
 assert ctx.potrf(T) == 0
 prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0)
 prob.workspace()
-for label, key, sep in (('approximate (52=0)', 0, False), ('exact, in front of the solve (52=1, default)', 1, False),
-                        ('approximate + gpk_gn_loss call', 0, True), ('exact again', 1, False)):
+for label, key, sep in (('approximate (52=0)', 0, False), ('exact, chain next to the END of the step (52=1, default)', 1, False),
+                        ('exact, in front of the solve (52=2)', 2, False), ('approximate + gpk_gn_loss call', 0, True), ('exact, default again', 1, False)):
     ctx.tune(52, key)
     z = ctx.array(z0)
     for _ in range(3):
@@ -35,6 +35,6 @@ for label, key, sep in (('approximate (52=0)', 0, False), ('exact, in front of t
     ctx.synchronize(); dt = (time.perf_counter() - t0) / n * 1e3
     pr = ctx.prof_read(); ctx.prof_enable(False)
     k = max(pr['steps'], 1)
-    print(f'{wl} {label:48s}: {dt:7.3f} ms/step  solve {pr["trsm_ms"]/k:.3f}  product+potrf {pr["syrk_ms"]/k:.3f}  tail {pr["trsv_update_ms"]/k:.3f}  loss[-1] {losses[-1]:.12e}', flush=True)
+    print(f'{wl} {label:58s}: {dt:7.3f} ms/step  solve {pr["trsm_ms"]/k:.3f}  product+potrf {pr["syrk_ms"]/k:.3f}  tail {pr["trsv_update_ms"]/k:.3f}  loss[-1] {losses[-1]:.12e}', flush=True)
     z.free()
 ctx.close()
