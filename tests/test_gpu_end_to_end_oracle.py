@@ -164,11 +164,11 @@ def test_config4_end_to_end_darcy():
     assert len(e.loss_hist) == len(hist_o) == cfg.GNsteps + 1
     assert all(v <= TOL for v in r.values()), r
     # loss history: nugget 1e-8 on two factors of order 6600 / 4800 and 8 compounded steps of an inverse problem (cond(H) ~ 1e11): the printed
-    # deviation is what two fp64 chains give (iterates above: <= 7e-8); bound 1e-3, the start value (no iteration involved) 1e-6
+    # deviation is what two fp64 chains give (iterates above: <= 7e-8; measured 2.7e-6 on the loss); bound 2e-5, the start value (no iteration involved) 1e-6
     dev = np.max(np.abs(np.asarray(e.loss_hist) / np.asarray(hist_o) - 1.0))
     print(f'[C4] loss history max rel. dev {dev:.2e} (start value {abs(e.loss_hist[0] / hist_o[0] - 1):.1e}); device {["%.8e" % v for v in e.loss_hist]}')
     assert e.loss_hist[0] == pytest.approx(hist_o[0], rel=1e-6)
-    np.testing.assert_allclose(e.loss_hist, hist_o, rtol=1e-3)
+    np.testing.assert_allclose(e.loss_hist, hist_o, rtol=2e-5)
 
 
 def test_burgers_notebook_statistical_kat():
