@@ -33,6 +33,15 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
     name=$(echo $pass | tr ' ' '+')
     timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_n10k_$name -- python3 $REPO/bench.py $N10K --steps 2 --warmup 1 > $OUT/pmc_n10k_$name.json 2> $OUT/pmc_n10k_$name.err
 done
+# BASELINE configs 3, 4 and 5-on-one-GPU: the same four PMC passes (round 5: no roofline.traffic of the line stays null)
+for wl in c3 c4 c5; do
+    EXTRA="--no-cpu-baseline"; [ $wl = c5 ] && EXTRA="--no-cpu-baseline --no-sharded-parity"
+    [ $wl = c5 ] && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $REPO/bench.py --workload $wl $EXTRA --steps 2 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2> $OUT/stats_$wl.err
+    for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+        name=$(echo $pass | tr ' ' '+')
+        timeout 900 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_${wl}_$name -- python3 $REPO/bench.py --workload $wl $EXTRA --steps 2 --warmup 1 > $OUT/pmc_${wl}_$name.json 2> $OUT/pmc_${wl}_$name.err
+    done
+done
 # (tools/summarize_potrf_pmc.py reads the MFMA-busy pass of the factorisation from pmc_n10k_SQ_VALU_MFMA_BUSY_CYCLES+GRBM_GUI_ACTIVE)
 # keep the merge-back small: only the stats and counter tables
 find $OUT -name "*kernel_trace.csv" -delete

@@ -153,10 +153,11 @@ def summarise(prefix, workload, suffix):
 
 
 # kernel-stats tables of the other single-workload runs (c3, c4, n10k) next to the config-2 one
-for wl in ('n10k', 'c3', 'c4'):
+for wl in ('n10k', 'c3', 'c4', 'c5'):
     st = one(f'stats_{wl}/**/*kernel_stats.csv')
     if st:
         shutil.copy(st, os.path.join(DST, f'{tag}_bench_{wl}_kernel_stats.csv'))
 summarise('', 'c2', '')
-if one('pmc_n10k_FETCH_SIZE/**/*counter_collection.csv'):
-    summarise('n10k_', 'n10k', '_n10k')
+for wl in ('n10k', 'c3', 'c4', 'c5'):
+    if one(f'pmc_{wl}_FETCH_SIZE/**/*counter_collection.csv'):
+        summarise(f'{wl}_', wl, f'_{wl}')
