@@ -72,6 +72,7 @@ struct GpkTune {
     int solve_splitk = 0;               // key 30: largest split-K factor tried for the updates of the inverted-block solve (0 = off)
     int potrf_pipeline_min_n = 2048;    // key 19: plain Cholesky pipelined for orders in [min, max] (max = 0: off, see gpk_i_potrf)
     int potrf_pipeline_max_n = 0;       // key 20: plain Cholesky pipelined for orders in [min, max] (max = 0: off, see gpk_i_potrf)
+    int potrf_lookahead = 0;            // key 54 (development build only): 1 = the two-partition plain Cholesky (orders of keys 19 / 20) in its right-looking look-ahead form (round 5: measured, not adopted) instead of the left-looking pipeline
     int potrf_ob = 512;                 // key 51: outer block width of the right-looking factorisation (multiple of 64)
     int pipeline = 1;                   // key 12: 0 = SYRK, then right-looking Cholesky, on one stream
     int pipeline_chain_cus = 32;        // key 13: CUs of the chain partition (rounded to a multiple of 32)

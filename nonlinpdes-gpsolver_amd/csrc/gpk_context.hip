@@ -193,7 +193,7 @@ extern "C" int gpk_tune(gpk_handle h, int key, int value) {
     GpkTune& t = h->tune;
 #ifndef GPK_DEV
     // values that select a superseded design: those kernels are not in this library (csrc/dev/, libgpk_dev.so)
-    if ((key == 5 && value == 0) || (key == 7 && value != 0) || (key == 21 && value != 1) || (key == 4 && value == 2) || key == 11)
+    if ((key == 5 && value == 0) || (key == 7 && value != 0) || (key == 21 && value != 1) || (key == 4 && value == 2) || key == 11 || (key == 54 && value != 0))
         return gpk_bad_arg(h, "gpk_tune: this variant exists only in the development build (libgpk_dev.so)");
 #endif
     switch (key) {
@@ -243,6 +243,7 @@ extern "C" int gpk_tune(gpk_handle h, int key, int value) {
         case 50: t.big_lower_min = value; return 0;
         case 51: t.potrf_ob = value; return 0;
         case 52: t.exact_loss = value; return 0;
+        case 54: t.potrf_lookahead = value; return 0;
         default: return gpk_bad_arg(h, "gpk_tune: unknown key");
     }
 }

@@ -1375,9 +1375,84 @@ static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     return 0;
 }
 
+#ifdef GPK_DEV                                                       // measured and not adopted (round 5): development build only
+// RIGHT-looking factorisation with look-ahead on the two CU partitions (round 5; gpk_tune key 54 = 1 selects it for the orders of keys 19 /
+// 20 instead of the left-looking pipeline above).  MEASURED, NOT ADOPTED (profiles/r05_potrf_lookahead.txt, tools/potrf_modes_probe.py): bit-identical
+// factor, but at order 8400 7.4 ms with a 64-CU chain partition / 9.1 ms with 32 CUs against 6.6 ms on one stream -- the tall fused panel kernels
+// run 1.75x / 2.5x longer on the partition (41.7 / 60.4 us instead of 23.8: two to three rounds of workgroups) and become the critical path while
+// the products lose a quarter / an eighth of the chip; 9600: 8.83 vs 8.78; 16000: 30.1 vs 29.7.  potrf_seq leaves the chip nearly idle during the panel chains (8 fused panel kernels of
+// ~22 us per 512 columns: 40 % of the factorisation at order 9600) and the left-looking pipeline pays for its overlap with skinny, long-K
+// block-column updates.  Here the trailing update stays the large rank-512 product it is in potrf_seq, cut in two: on the GEMM partition,
+// block k's update of the NEXT block column first (rows x 512 x 512), then -- while the chain partition already factors that column -- its
+// update of everything to the right.  Per block: chain_k (C) -> next-column update (G) -> chain_{k+1} (C) || rest of update k (G).
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve);
+static int potrf_lookahead(gpk_handle h, double* A, int n, int lda, int pivot_base) {
+    const int OB = (h->tune.potrf_ob >= 64 && h->tune.potrf_ob % 64 == 0) ? h->tune.potrf_ob : 512;
+    const int J = gpk_ceil_div(n, OB);
+    if (J < 3) return potrf_seq(h, A, n, lda, pivot_base);
+    GPK_TRY(pipe_setup(h, 2 * (size_t)J + 1, 0, true));
+    const hipStream_t main_s = h->stream, G = h->pipe_g, C = h->pipe_c;
+    hipEvent_t* ev_col = h->pipe_ev.data();                          // [J]: block column j carries every update of the blocks before it
+    hipEvent_t* ev_chain = h->pipe_ev.data() + J;                    // [J]: block column j is factored
+    hipEvent_t ev_fork = h->pipe_ev[2 * J];
+    auto fail = [&](hipError_t e, const char* what) {
+        h->stream = main_s; h->no_sk = 0;
+        (void)hipStreamSynchronize(G); (void)hipStreamSynchronize(C);
+        return gpk_fail(h, e, what, __FILE__, __LINE__);
+    };
+#define LA_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail(e__, #call); } while (0)
+    // block column 0: nothing to overlap with -- on the whole chip, before the fork
+    int rc = gpk_i_potrf_panel(h, A, n, std::min(OB, n), lda, pivot_base);
+    if (rc) return rc;
+    LA_HIP(hipEventRecord(ev_fork, main_s));
+    LA_HIP(hipStreamWaitEvent(G, ev_fork, 0));
+    LA_HIP(hipStreamWaitEvent(C, ev_fork, 0));
+    for (int j = 0; j < J && rc == 0; ++j) {
+        const int k0 = j * OB, ob = std::min(OB, n - k0), k1 = k0 + ob, rest = n - k1;
+        if (j > 0) {                                                 // chain of block column j on the chain partition
+            h->stream = C; h->no_sk = 1;
+            LA_HIP(hipStreamWaitEvent(C, ev_col[j], 0));
+            rc = gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, ob, lda, pivot_base + k0);
+            h->no_sk = 0;
+            if (rc) break;
+            LA_HIP(hipEventRecord(ev_chain[j], C));
+        }
+        if (rest <= 0) break;
+        h->stream = G;
+        if (j > 0) LA_HIP(hipStreamWaitEvent(G, ev_chain[j], 0));
+        const double* P = A + (long)k1 * lda + k0;                   // rows k1.. of the factored block column j
+        const int ob1 = std::min(OB, rest);
+        // the next block column first (its top square is a diagonal block: tiles above the diagonal are not computed) ...
+        rc = gpk_i_gemm(h, false, true, rest, ob1, ob, -1.0, P, lda, P, lda, 1.0, A + (long)k1 * lda + k1, lda, false, 0, false, true);
+        if (rc) break;
+        LA_HIP(hipEventRecord(ev_col[j + 1], G));
+        // ... then everything to its right, next to the chain of block column j + 1
+        const int rest2 = rest - ob1;
+        if (rest2 > 0) {
+            const double* P2 = A + (long)(k1 + ob1) * lda + k0;
+            rc = gpk_i_gemm(h, false, true, rest2, rest2, ob, -1.0, P2, lda, P2, lda, 1.0, A + (long)(k1 + ob1) * lda + (k1 + ob1), lda, true);
+            if (rc) break;
+        }
+    }
+    h->stream = main_s; h->no_sk = 0;
+    if (rc) { (void)hipStreamSynchronize(G); (void)hipStreamSynchronize(C); return rc; }
+    LA_HIP(hipEventRecord(ev_fork, G));                              // (re-used: everything the GEMM partition was given)
+    LA_HIP(hipStreamWaitEvent(main_s, ev_fork, 0));
+    LA_HIP(hipStreamWaitEvent(main_s, ev_chain[J - 1], 0));
+#undef LA_HIP
+    return 0;
+}
+
+#endif
+
 int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     if (h->tune.pipeline && !h->pipe_unavailable && n >= h->tune.potrf_pipeline_min_n && n <= h->tune.potrf_pipeline_max_n && h->num_cu >= 64)
+    {
+#ifdef GPK_DEV
+        if (h->tune.potrf_lookahead) return potrf_lookahead(h, A, n, lda, pivot_base);
+#endif
         return potrf_pipelined(h, nullptr, 0, 0, n, 0, A, lda, nullptr, pivot_base);
+    }
     return potrf_seq(h, A, n, lda, pivot_base);
 }
 
@@ -1402,7 +1477,6 @@ int gpk_i_potrf(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 
 // Block columns of the pipelined factorisation: a first block of h->tune.pipeline_w0 columns (the chain can only start once its product is
 // there), then blocks of h->tune.pipeline_ob columns; widths are multiples of the panel width, at most 512.
-static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve = true);
 static std::vector<int> pipe_blocks(gpk_handle h, int nc) {
     auto norm = [](int w) { w = (w / NB) * NB; return w < NB ? NB : (w > 512 ? 512 : w); };
     std::vector<int> b{0};
@@ -1420,7 +1494,7 @@ static std::vector<int> pipe_blocks(gpk_handle h, int nc) {
 // nothing.
 int gpk_i_pipe_streams(gpk_handle h) { return pipe_setup(h, 0, 0, false); }
 
-static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve) {
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve = true) {
     // multiples of 32: bits 8k .. 8k+7 of the mask are one CU of shader engine k mod 4 on each of the 8 XCDs, so 32 bits take one CU from
     // every shader engine; other sizes leave the engines uneven (measured: 48 behaves like 32, 80 like 64)
     int c = ((h->tune.pipeline_chain_cus + 16) / 32) * 32;
