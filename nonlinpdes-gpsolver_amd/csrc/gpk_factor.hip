@@ -1375,6 +1375,7 @@ static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     return 0;
 }
 
+static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve);
 #ifdef GPK_DEV                                                       // measured and not adopted (round 5): development build only
 // RIGHT-looking factorisation with look-ahead on the two CU partitions (round 5; gpk_tune key 54 = 1 selects it for the orders of keys 19 /
 // 20 instead of the left-looking pipeline above).  MEASURED, NOT ADOPTED (profiles/r05_potrf_lookahead.txt, tools/potrf_modes_probe.py): bit-identical
@@ -1385,7 +1386,6 @@ static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
 // block-column updates.  Here the trailing update stays the large rank-512 product it is in potrf_seq, cut in two: on the GEMM partition,
 // block k's update of the NEXT block column first (rows x 512 x 512), then -- while the chain partition already factors that column -- its
 // update of everything to the right.  Per block: chain_k (C) -> next-column update (G) -> chain_{k+1} (C) || rest of update k (G).
-static int pipe_setup(gpk_handle h, size_t nev, size_t ntev, bool reserve);
 static int potrf_lookahead(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     const int OB = (h->tune.potrf_ob >= 64 && h->tune.potrf_ob % 64 == 0) ? h->tune.potrf_ob : 512;
     const int J = gpk_ceil_div(n, OB);
