@@ -1070,6 +1070,13 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
         chol_fl = (nz + 1) ** 3 / 3.0
         executed = solve_fl + prod_fl + chol_fl
         ex_rate = executed * steps / elapsed / 1e12
+        # HBM-side bytes per step of the step's two product families (solve-phase launches + the product S^T S) from the stored PMC passes of
+        # THIS workload on one GPU (profiles/rNN_pmc_*_<workload>.json); null with more than one rank (no pass exists) or without a stored pass
+        t1, s1 = stored_pmc_traffic('trsm_gemm', workload)
+        t2, s2 = stored_pmc_traffic('syrk', workload)
+        step_traffic = (t1 + t2) if (world == 1 and t1 is not None and t2 is not None) else None
+        step_traffic_source = (f'solve launches: {s1}; product: {s2}' if step_traffic is not None else
+                               ('no stored PMC pass for more than one rank' if world > 1 else f'{s1}; {s2}'))
         out = {
             'metric': 'Gauss-Newton steps/sec + L2 error, NonLinElliptic2d at N_domain points',
             'value': steps / elapsed, 'unit': 'GN steps/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup_run,
@@ -1091,7 +1098,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
             'mode_probe': mode_probe or None, 'preflight': preflight, 'wall_s': wall,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step: solve + product + Cholesky of Hb), flops EXECUTED summed over the ranks',
                          'achieved': ex_rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
-                         'frac': ex_rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': None,
+                         'frac': ex_rate / (FP64_MFMA_PEAK_TFLOPS * world), 'traffic': step_traffic, 'traffic_source': step_traffic_source,
                          'flops_per_step': {'solve': solve_fl, 'product': prod_fl, 'cholesky_H': chol_fl},
                          'dense_equivalent_tflops': rate},
             'roofline_cholesky_theta': {'bound': 'mfma', 'kernel': 'sharded Cholesky of Theta (panel kernels + trailing GEMM updates; broadcasts at N > 1)',
