@@ -99,6 +99,10 @@ def test_rccl_binding_comes_up_with_one_rank():
     ok = C.c_int()
     rc = ctx.lib.gpk_mg_selftest(h, C.byref(ok))                  # the REAL ncclBroadcast / ncclAllGather, one rank: argument order, type codes
     assert rc == 0 and ok.value == 1, ctx.lib.gpk_last_error(ctx.h).decode()
+    bms, ams, seen = (C.c_double * 1)(), C.c_double(), C.c_int()  # (round 5) gpk_mg_preflight through the real RCCL entry points, one rank
+    rc = ctx.lib.gpk_mg_preflight(h, 64 << 20, 2, bms, C.byref(ams), C.byref(seen))
+    assert rc == 0 and seen.value == 1 and bms[0] > 0 and ams.value > 0, ctx.lib.gpk_last_error(ctx.h).decode()
+    print(f'[rccl] preflight, one rank: broadcast of 64 MB {bms[0]:.3f} ms, all-gather {ams.value:.3f} ms')
     assert ctx.lib.gpk_mg_destroy(h) == 0
     ctx.close()
 
@@ -169,6 +173,9 @@ WORKER = textwrap.dedent('''
     sol_ref, hist_ref = O.gn_method(sysm, [Lref], z0, 3, 1)
     mgpu = MultiGpu(ctx, rank, world, panel=128, comm='staged')
     assert mgpu.selftest()
+    pf = mgpu.preflight(1 << 20, 1)                               # (round 5) the bandwidth preflight bench.py runs before a sharded run
+    assert pf['ranks_seen_by_rccl'] == world and len(pf['bcast_ms_by_root']) == world
+    assert all(m > 0 for m in pf['bcast_ms_by_root']) and pf['allgather_ms'] > 0 and all(v > 0 for v in pf['bcast_gbs_by_root'])
     mgpu.set_option('col_align', 64)
     results = []
     for lookahead, shard_hb, overlap_s in ((0, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1)):
