@@ -123,6 +123,8 @@ struct gpk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int* d_info = nullptr;          // device int: first non-positive pivot (1-based), 0 = none
     double* d_scalars = nullptr;    // small device scratch for reductions (16 doubles)
+    double* h_pinned = nullptr;     // 8 doubles of pinned host memory: where the end-of-step scalars (loss, pivot status) land -- a copy into
+                                    // pageable memory goes through a staging buffer and a second synchronisation
     int* d_flags = nullptr;         // per-block "solved" epochs of the fused single-vector triangular solve (GPK_MAX_TRSV_BLOCKS ints)
     int trsv_epoch = 0;
     void* d_trsv_gran = nullptr;    // {value, epoch} granules of the fused triangular solve with data-tagged hand-offs (64 per block), allocated on first use

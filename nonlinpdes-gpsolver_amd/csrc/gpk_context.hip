@@ -31,6 +31,7 @@ extern "C" int gpk_create(int device, gpk_handle* out) {
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_info, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_scalars, 64 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->h_pinned, 8 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMemset(h->d_info, 0, sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_obflags, 64 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(h->d_obflags, 0, 64 * sizeof(int));
@@ -57,6 +58,7 @@ extern "C" int gpk_destroy(gpk_handle h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->d_info) (void)hipFree(h->d_info);
     if (h->d_scalars) (void)hipFree(h->d_scalars);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->d_flags) (void)hipFree(h->d_flags);
     if (h->d_trsv_gran) (void)hipFree(h->d_trsv_gran);
     if (h->d_loss_work) (void)hipFree(h->d_loss_work);

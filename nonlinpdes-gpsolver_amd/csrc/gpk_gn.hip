@@ -660,12 +660,13 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     }
     GPK_LAUNCH_CHECK(h);
     GPK_PROF_MARK(h, 4);
-    int info = 0;
-    double loss = 0.0;
-    GPK_HIP(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    // the two host scalars of the step through pinned memory (h_pinned[0] = loss, the int behind h_pinned[1] = pivot status)
+    GPK_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (exact_late) GPK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_loss[1], 0));
-    GPK_HIP(h, hipMemcpyAsync(&loss, exact ? h->d_scalars + 8 : d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GPK_HIP(h, hipMemcpyAsync(h->h_pinned, exact ? h->d_scalars + 8 : d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
+    int info = *reinterpret_cast<const int*>(h->h_pinned + 1);
+    const double loss = h->h_pinned[0];
     if (h->prof) {
         for (int i = 0; i < 4; ++i) {
             float ms = 0.f;
