@@ -175,8 +175,8 @@ int gpk_gn_dims(const gpk_gn_problem* host_prob, int* nz, int* s_rows);
 /* Workspace query (pure host function, no device): what a caller has to allocate for gpk_gn_step / gpk_gn_hessian_grad and what the
  * handle will reserve by itself.  lds: the leading dimension the caller intends to use for S and Hb (0 = the smallest admissible one,
  * nz + 1 rounded up to 16 doubles; returned in *host_lds).  *S_bytes = s_rows * lds * 8, *Hb_bytes = (nz + 1) * lds * 8, *delta_bytes =
- * nz * 8, *handle_bytes = the out-of-place solve buffer the handle grows on first use when the inverted diagonal blocks are supplied
- * (s_rows * lds * 8, else 0).  Any output pointer may be NULL. */
+ * nz * 8, *handle_bytes = the out-of-place solve buffer the handle grows on first use when the inverted diagonal blocks of EVERY factor are
+ * supplied (s_rows * lds * 8 -- whatever dinv_block says, 0 meaning 256 -- else 0; + s_rows * 8 for the exact in-step loss).  Any output pointer may be NULL. */
 int gpk_gn_worksize(const gpk_gn_problem* host_prob, int lds, int* host_lds, size_t* S_bytes, size_t* Hb_bytes, size_t* delta_bytes,
                     size_t* handle_bytes);
 /* (With host_prob->Dinv set, S is scratch and the solved block lives in the handle's workspace.) */

@@ -541,13 +541,17 @@ extern "C" int gpk_gn_worksize(const gpk_gn_problem* p, int lds, int* host_lds, 
     const int nc = d.nz + 1;
     if (lds == 0) lds = ((nc + 15) / 16) * 16;
     if (lds < nc) return GPK_ERR_ARG;
-    bool dinv = p->dinv_block > 0;
+    // as assemble_normal_equations decides it: the out-of-place GEMM-only solve runs whenever EVERY factor comes with its inverted diagonal
+    // blocks (dinv_block = 0 means 256 there too); the figure assumes the default gpk_tune(10, 1) -- with the substitution schedule forced
+    // the handle reserves nothing
+    bool dinv = false;
+    for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && d.g[k].Dinv) dinv = true;
     for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) dinv = false;
     if (host_lds) *host_lds = lds;
     if (S_bytes) *S_bytes = (size_t)d.rows * lds * sizeof(double);
     if (Hb_bytes) *Hb_bytes = (size_t)nc * lds * sizeof(double);
     if (delta_bytes) *delta_bytes = (size_t)d.nz * sizeof(double);
-    if (handle_bytes) *handle_bytes = dinv ? (size_t)d.rows * lds * sizeof(double) : 0;
+    if (handle_bytes) *handle_bytes = (dinv ? (size_t)d.rows * lds * sizeof(double) : 0) + (size_t)d.rows * sizeof(double);
     return 0;
 }
 

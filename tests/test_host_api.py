@@ -221,7 +221,19 @@ def test_gn_worksize_query_runs_without_a_device():
             assert lib.gpk_gn_worksize(C.byref(ps), 0, C.byref(ld), C.byref(sb), C.byref(hb), C.byref(db), C.byref(wb)) == 0
             assert ld.value % 16 == 0 and nz.value + 1 <= ld.value < nz.value + 17
             assert sb.value == rows.value * ld.value * 8 and hb.value == (nz.value + 1) * ld.value * 8 and db.value == nz.value * 8
-            assert wb.value == 0                                  # no inverted diagonal blocks supplied: nothing reserved by the handle
+            assert wb.value == rows.value * 8                      # no inverted diagonal blocks supplied: only the vector of the exact in-step loss
+            # with the factors and their inverted diagonal blocks supplied the handle also reserves the out-of-place solve buffer -- whatever
+            # dinv_block says (0 means 256 to the step): the query mirrors what assemble_normal_equations decides (advisor, round 4)
+            for blk in (0, 1024):
+                ps.L, ps.ldl, ps.Dinv, ps.dinv_block = 4096, rows.value, 8192, blk          # (never dereferenced: host function)
+                if system == 3:
+                    ps.L2, ps.ldl2, ps.Dinv2 = 4096, rows.value, 8192
+                assert lib.gpk_gn_worksize(C.byref(ps), 0, None, None, None, None, C.byref(wb)) == 0
+                assert wb.value == rows.value * ld.value * 8 + rows.value * 8
+            if system == 3:                                       # one factor without its blocks: the substitution schedule, nothing reserved
+                ps.Dinv2 = None
+                assert lib.gpk_gn_worksize(C.byref(ps), 0, None, None, None, None, C.byref(wb)) == 0 and wb.value == rows.value * 8
+            ps.L = ps.Dinv = ps.L2 = ps.Dinv2 = None
             assert lib.gpk_gn_worksize(C.byref(ps), nz.value, None, None, None, None, None) < 0      # lds < nz + 1
     ps = GNProblemStruct(); ps.system = 99; ps.Nd = 10
     assert lib.gpk_gn_worksize(C.byref(ps), 0, None, None, None, None, None) < 0
