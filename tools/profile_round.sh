@@ -15,7 +15,9 @@ OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ONE="--no-sharded-config --no-cpu-baseline --no-structured --no-n10k --no-c3c4"
-timeout 1200 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
+# (the full result object of every bench run goes to GPK_BENCH_DETAIL_DIR: the plain run's is kept, the profiled runs' go to /tmp)
+GPK_BENCH_DETAIL_DIR=$OUT timeout 1200 python3 $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+export GPK_BENCH_DETAIL_DIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 # the value's workload alone (config 2): per-kernel averages here are directly comparable with bench.py's roofline object
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -- python3 $REPO/bench.py $ONE > $OUT/bench_c2_under_rocprof.json 2> $OUT/stats_c2.err

@@ -43,6 +43,8 @@ if stats:                                                        # default comma
 stats = one('stats_c2/**/*kernel_stats.csv')
 if stats:                                                        # --no-sharded-config: the value's workload alone
     shutil.copy(stats, os.path.join(DST, f'{tag}_bench_kernel_stats.csv'))
+if os.path.exists(os.path.join(SRC, 'bench_detail.json')):       # the full result object of the plain run (the line itself is its compact form)
+    shutil.copy(os.path.join(SRC, 'bench_detail.json'), os.path.join(DST, f'{tag}_bench_detail.json'))
 for src, dst in [('bench.json', f'{tag}_bench.json'), ('bench_under_rocprof.json', f'{tag}_bench_under_rocprof.json')]:
     p = os.path.join(SRC, src)
     if os.path.exists(p):
@@ -86,10 +88,12 @@ def summarise(prefix, workload, suffix):
     if fa and wa:
         summary['assemble_kernel'] = {'WRITE_SIZE_KiB': mean(wa, 'WRITE_SIZE'), 'FETCH_SIZE_KiB_raw': mean(fa, 'FETCH_SIZE'),
                                       'write_bytes': mean(wa, 'WRITE_SIZE') * 1024, 'avg_duration_us_under_pmc': mean(wa, 'dur_us')}
-    bench = os.path.join(DST, f'{tag}_bench.json')
+    bench = os.path.join(DST, f'{tag}_bench_detail.json')
+    if not os.path.exists(bench):
+        bench = os.path.join(DST, f'{tag}_bench.json')
     if os.path.exists(bench):
         bj = json.load(open(bench))
-        bj = bj if workload == 'c2' else bj.get(workload, {})
+        bj = bj if workload == 'c2' else bj.get({'c5': 'sharded_config'}.get(workload, workload), {})
         rl = bj.get('roofline_syrk') or bj.get('roofline', {})
         summary['algorithmic_flops_per_launch'] = rl.get('flops_per_launch')
         summary['note_launches'] = ('since round 2 the product is issued as one launch per 512-column block (pipelined with the '
@@ -135,7 +139,7 @@ def summarise(prefix, workload, suffix):
         trsm['l2_hit_rate'] = h / (h + m)
     if os.path.exists(bench):
         bj = json.load(open(bench))
-        bj = bj if workload == 'c2' else bj.get(workload, {})
+        bj = bj if workload == 'c2' else bj.get({'c5': 'sharded_config'}.get(workload, workload), {})
         trsm['executed_flops_per_step_model'] = (bj.get('roofline') or {}).get('flops_per_step')
     # kernel-trace cross-check of the live figure: sum of the NN launches per step in the stats run of the value's workload
     st = os.path.join(DST, f'{tag}_bench_kernel_stats.csv' if workload == 'c2' else f'{tag}_bench_{workload}_kernel_stats.csv')
