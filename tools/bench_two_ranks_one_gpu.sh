@@ -12,10 +12,11 @@ for engine in native python; do
   done
   wait
   echo "== executor: $engine"
-  grep "^{" gpurun_out/bench2_${engine}_rank0.log | python -c "
+  grep "^{" gpurun_out/bench2_${engine}_rank0.log | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read())
 print('value (sharded config 5)', d['value'], 'n_gpus', d['n_gpus'], d['scaling'], 'ms/step', d['ms_per_step'], 'pts_L2_err', d['l2_error']['pts_L2_err'])
 print('vs_1gpu', d.get('vs_1gpu'), 'one GPU in the same job:', (d.get('one_gpu_same_job') or {}).get('ms_per_step'), 'executor:', d['config'].get('executor'))
+print('line bytes', len(json.dumps(d, separators=(',', ':'))), 'value_workload', d.get('value_workload'), 'preflight', d.get('preflight'))
 print('mode_probe', d.get('mode_probe')); print('parity', {k: (d.get('parity') or {}).get(k) for k in ('z1_rel_dev_vs_B2', 'ok', 'skipped')}, 'parity_failed', d.get('parity_failed'))
 print('replicas_c2', {k: (d.get('replicas_c2') or {}).get(k) for k in ('value', 'n_gpus', 'scaling', 'ms_per_step', 'error')})"
   tail -2 gpurun_out/bench2_${engine}_rank1.log
