@@ -241,3 +241,40 @@ def test_class_api_loss_history_is_exact(monkeypatch):
         gpk.load_library().gpk_debug_set(52, 1)
     np.testing.assert_array_equal(a.sol_sampled_pts, e.sol_sampled_pts)
     np.testing.assert_allclose(a.loss_hist, e.loss_hist, rtol=1e-5)
+
+
+def test_step_with_the_concurrent_loss_chain_is_bitwise_repeatable():
+    """Round 5: the exact loss of gpk_gn_step runs its substitution chain on the GEMM partition's stream NEXT TO the last panel chain of the
+    pipelined phase and the backward solve of the tail (two single-vector solves at once, each with its own granule set).  Concurrency must
+    not show in the numbers: the same five steps, 12 times over, give bit-identical loss histories and iterates (pipelined size: n_z = 1500),
+    and the values are those of the serial placement (gpk_tune(52, 2): the chain in front of the solve)."""
+    import gpk
+    from oracle import gp_oracle as O
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(3)
+    Nd, Nb = 1500, 200
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    z0 = rng.normal(size=Nd)
+    T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-10, 'adaptive')
+    assert ctx.potrf(T) == 0
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0)
+    prob.workspace()
+
+    def run():
+        z = ctx.array(z0)
+        hist = [ctx.gn_step(prob, z)[0] for _ in range(5)]
+        sol = z.download(); z.free()
+        return hist, sol
+    ref = run()
+    for _ in range(11):
+        h, s = run()
+        assert h == ref[0] and np.array_equal(s, ref[1])
+    ctx.tune(52, 2)
+    h, s = run()
+    ctx.tune(52, 1)
+    assert h == ref[0] and np.array_equal(s, ref[1])
+    sysm = O.EllipticSystem(1.0, 3.0, f, g)
+    L = np.tril(T.download())
+    assert ref[0][0] == pytest.approx(O.loss(sysm, [L], z0), rel=1e-12)
+    prob.release_workspace(); T.free(); ctx.close()
