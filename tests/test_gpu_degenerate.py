@@ -160,3 +160,45 @@ def test_round4_entry_points_reject_bad_arguments_and_handle_edges():
         assert np.linalg.norm(outs[0][0] - outs[1][0]) <= 1e-9 * np.linalg.norm(outs[1][0])
         assert outs[0][1] == pytest.approx(outs[1][1], rel=1e-10)
     ctx.close()
+
+
+def test_round5_entry_points_reject_bad_arguments_and_handle_edges():
+    """gpk_mg_preflight without a communicator / with a buffer below one element / null outputs; gpk_tune keys of round 5 (52: the loss
+    gpk_gn_step reports; 54 exists only in the development build); the exact in-step loss on a problem smaller than one 64-equation block and
+    with the substitution schedule (no inverted blocks): same number as gpk_gn_loss."""
+    import gpk
+    from oracle import gp_oracle as O
+    ctx = gpk.Context(0)
+    h = C.c_void_p()
+    assert ctx.lib.gpk_mg_create(ctx.h, 0, 1, 512, C.byref(h)) == 0
+    bms, ams, seen = (C.c_double * 1)(), C.c_double(), C.c_int()
+    assert ctx.lib.gpk_mg_preflight(h, 1 << 20, 1, bms, C.byref(ams), C.byref(seen)) < 0          # no communicator bound
+    assert 'no communicator' in ctx.lib.gpk_last_error(ctx.h).decode()
+    assert ctx.lib.gpk_mg_preflight(h, 4, 1, bms, C.byref(ams), C.byref(seen)) < 0                # less than one double
+    assert ctx.lib.gpk_mg_preflight(h, 1 << 20, 0, bms, C.byref(ams), C.byref(seen)) < 0          # no repetitions
+    assert ctx.lib.gpk_mg_preflight(h, 1 << 20, 1, None, C.byref(ams), C.byref(seen)) < 0
+    assert ctx.lib.gpk_mg_preflight(None, 1 << 20, 1, bms, C.byref(ams), C.byref(seen)) < 0
+    assert ctx.lib.gpk_mg_destroy(h) == 0
+    assert ctx.lib.gpk_tune(ctx.h, 54, 1) < 0 and 'development build' in ctx.lib.gpk_last_error(ctx.h).decode()
+    assert ctx.lib.gpk_tune(ctx.h, 54, 0) == 0
+    rng = np.random.RandomState(12)
+    for Nd, Nb, dinv in ((20, 6, False), (20, 6, 256), (150, 0, False), (333, 41, 256)):
+        Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2)) if Nb else np.zeros((0, 2))
+        f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1]) if Nb else np.zeros(0)
+        T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.3, Xd, Xb, 1e-8, 'adaptive')
+        assert ctx.potrf(T) == 0
+        prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0, dinv=dinv)
+        z0 = rng.normal(size=Nd)
+        want = ctx.gn_loss(prob, ctx.array(z0))
+        for mode in (1, 2):                                        # chain next to the end of the step / in front of the solve
+            ctx.tune(52, mode)
+            z = ctx.array(z0)
+            got, info = ctx.gn_step(prob, z)
+            assert info == 0 and got == pytest.approx(want, rel=1e-13), (Nd, Nb, dinv, mode)
+        ctx.tune(52, 0)
+        z = ctx.array(z0)
+        approx, _ = ctx.gn_step(prob, z)                           # the free number of rounds 2-4: equal to a few digits beyond the tolerance of the loss histories
+        assert approx == pytest.approx(want, rel=1e-6)
+        ctx.tune(52, 1)
+        prob.release_workspace(); T.free()
+    ctx.close()
