@@ -166,6 +166,7 @@ def test_round5_entry_points_reject_bad_arguments_and_handle_edges():
     """gpk_mg_preflight without a communicator / with a buffer below one element / null outputs; gpk_tune keys of round 5 (52: the loss
     gpk_gn_step reports; 54 exists only in the development build); the exact in-step loss on a problem smaller than one 64-equation block and
     with the substitution schedule (no inverted blocks): same number as gpk_gn_loss."""
+    import ctypes as C
     import gpk
     from oracle import gp_oracle as O
     ctx = gpk.Context(0)
