@@ -339,11 +339,11 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
     dev_first = first_step_on_device(ctx, prob, z0)               # for `parity` (also the first, code-object-loading step)
     # A timed step is what the product's GN_method executes per iteration (nonlinpdes-gpsolver_amd/src/PDEs.py, _gn_iterate; the
     # reference's src/PDEs.py:117-127 = Hessian + gradient + solve + update + one loss evaluation): gpk_gn_step, which since round 5
-    # returns the loss of the iterate it starts from by true substitution (exact; one vector solved in front of the solve phase),
+    # returns the loss of the iterate it starts from by true substitution (exact; one vector, its chain beside the end of the step),
     # so that one call IS one reference iteration.  GPK_SEPARATE_LOSS=1 -- in the product and here -- is round 4's sequence:
     # gpk_gn_step followed by a gpk_gn_loss call of its own.
     with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'
-    losses = [ctx.gn_loss(prob, z)]
+    losses = [ctx.gn_loss(prob, z)] if with_loss else []          # (the in-step value of the first step already IS J(z_0): no double entry)
     loss_s = 0.0
 
     def product_step(timed=False):
@@ -737,7 +737,7 @@ def run_system(args, workload, steps=None, warmup=None):
     dev_first = first_step_on_device(ctx, prob, z0)
     z = ctx.array(z0)
     with_loss = os.environ.get('GPK_SEPARATE_LOSS', '0') == '1'       # (as in run_single: the product's per-iteration sequence)
-    losses = [ctx.gn_loss(prob, z)]
+    losses = [ctx.gn_loss(prob, z)] if with_loss else []          # (the in-step value of the first step already IS J(z_0): no double entry)
     loss_s = 0.0
 
     def product_step(timed=False):
@@ -1056,6 +1056,18 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
                                 coeff.data_ptr(), ext.data_ptr()))
     torch.cuda.synchronize()
     test_l2 = float(np.sqrt(np.sum((u_true(Xt[:, 0], Xt[:, 1]) - ext.cpu().numpy()) ** 2) / Xt.shape[0]))
+    # the Cholesky of the bordered matrix alone (one rank only: an input of the multi-GPU model, bench_model.py): its time does not depend
+    # on the data, so it is taken on the identity of that order in Hb (free after the last step)
+    potrf_hb_ms = None
+    if world == 1:
+        Hb.zero_(); Hb.diagonal().fill_(1.0)
+        ops.potrf(Hb, 0, nz + 1)                                  # (warm)
+        Hb.zero_(); Hb.diagonal().fill_(1.0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ops.potrf(Hb, 0, nz + 1)
+        torch.cuda.synchronize(); potrf_hb_ms = 1e3 * (time.perf_counter() - t0)
+    if not with_loss:                                             # close the history: the in-step value is the loss of the iterate a step STARTS from
+        losses.append(loss_of_iterate())
     out = None
     if rank == 0:
         rate = f1_flops(N, nz) * steps / elapsed / 1e12
@@ -1095,6 +1107,7 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
                          'loss_first': losses[0], 'loss_last': losses[-1], 'chol_info': info},
             'f1_tflops': rate,
             'one_time_ms': {'assembly_per_rank': asm_ms, 'cholesky_theta_sharded': chol_ms, 'cholesky_theta_first_call': chol_first_ms, 'diagonal_block_inverses': dinv_ms},
+            'cholesky_hb_alone_ms': potrf_hb_ms,
             'mode_probe': mode_probe or None, 'preflight': preflight, 'wall_s': wall,
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_f64_kernel (whole step: solve + product + Cholesky of Hb), flops EXECUTED summed over the ranks',
                          'achieved': ex_rate, 'peak': FP64_MFMA_PEAK_TFLOPS * world, 'unit': 'TFLOP/s',
@@ -1141,9 +1154,20 @@ def main():
     ap.add_argument('--no-replicas', action='store_true', help='N > 1: skip the secondary measurement of N independent config-2 replicas')
     ap.add_argument('--sharded-path', action='store_true', help='use the multi-rank schedule for the primary workload')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # the bare command `python3 bench.py --gpus N ...`: start the N ranks ourselves (bench_launch.py).  This process has made
+        # no GPU call and makes none: the ranks are fresh child processes, rank 0's compact line is relayed as our last stdout line.
+        import bench_launch
+        sys.exit(bench_launch.launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f'--gpus {args.gpus} needs {args.gpus} ranks: launch with python -m torch.distributed.run --nproc-per-node {args.gpus} ...')
+        sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch either the bare command (it starts its own ranks) or '
+                 f'python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...')
+    if os.environ.get('GPK_BENCH_STUBS'):
+        # CPU flow tests only (tests/test_bench_flow.py): a file that REPLACES the measuring functions of this module with stand-ins
+        # so that the launch / rendezvous / one-line logic runs without a GPU.  The line says so: `data` is not "synthetic".
+        with open(os.environ['GPK_BENCH_STUBS']) as fh:
+            exec(compile(fh.read(), os.environ['GPK_BENCH_STUBS'], 'exec'), globals())
     use_pg = world > 1 or os.environ.get('GPK_FORCE_PG') == '1'
     if use_pg:
         import torch
@@ -1157,8 +1181,26 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     SECONDARY_KEYS = ('value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'config', 'l2_error', 'f1_tflops', 'phases_ms_per_step',
                       'one_time_ms', 'roofline', 'roofline_syrk', 'roofline_assembly', 'roofline_cholesky_theta', 'flops_counted_by_library',
-                      'step_executed', 'mode_probe', 'cpu_baseline', 'parity')
+                      'step_executed', 'mode_probe', 'cpu_baseline', 'parity', 'cholesky_hb_alone_ms')
     pick = lambda d: {k: d[k] for k in SECONDARY_KEYS if k in d}
+
+    def prediction(one, preflight, ranks):
+        """bench_model.table from THIS job's 1-GPU point of config 5 (`one`: a run_sharded result on one rank) and the preflight of the bound
+        collectives (None at N = 1: one xGMI link x 0.8 assumed) -- what the multi-GPU choices should take, printed before / beside what they do"""
+        import bench_model
+        one_gpu = None
+        try:
+            if isinstance(one, dict) and one.get('ms_per_step'):
+                one_gpu = {'step_ms': one['ms_per_step'], 'cholesky_theta_ms': one['one_time_ms']['cholesky_theta_sharded'],
+                           'source': 'the 1-GPU point of config 5 measured in this job'}
+                if one.get('cholesky_hb_alone_ms'):
+                    one_gpu['cholesky_hb_ms'] = one['cholesky_hb_alone_ms']
+                fl = one['roofline'].get('flops_per_step') if isinstance(one.get('roofline'), dict) else None
+                if isinstance(fl, dict):
+                    one_gpu.update(solve_flops=fl['solve'], product_flops=fl['product'])
+            return bench_model.table(one_gpu=one_gpu, fabric=bench_model.fabric_from_preflight(preflight), ranks=ranks)
+        except Exception as e:                                    # noqa: BLE001 -- a model, never a reason to lose the measurement
+            return {'error': f'{type(e).__name__}: {e}'}
 
     def contract_line(obj, n_gpus, scaling):
         """a run_system result dressed as the driver's line"""
@@ -1210,6 +1252,17 @@ def main():
             else:
                 out['one_gpu_same_job'] = solo
                 out['vs_1gpu'] = None
+            # the host model beside the measurement (bench_model.py): what this rank count should have taken, per choice
+            out['predicted'] = prediction(solo, out.get('preflight'), tuple(sorted({2, 4, 8, world})))
+            mine = out['predicted'].get(str(world)) if isinstance(out['predicted'], dict) else None
+            if isinstance(mine, dict):
+                out['predicted_vs_1gpu'] = mine.get('predicted_vs_1gpu')
+                mp = out.get('mode_probe')
+                if isinstance(mp, dict):
+                    for key, src in (('cholesky_theta_ms', 'cholesky_theta_ms'), ('step_ms_by_cholesky_of_Hb', 'cholesky_of_Hb_ms'),
+                                     ('step_ms_by_exchange_of_S', 'exchange_of_S_ms')):
+                        if isinstance(mp.get(key), dict):
+                            mp[key]['expected_ms'] = mine.get(src)
             out['value_workload'] = 'c5'
             out['scaling_series'] = ('BASELINE config 5, strong scaling: this line\'s `value` at n_gpus > 1; at n_gpus = 1 the default line reports config 2 as '
                                      '`value` (the configuration the metric is quoted on, it fits one GPU) and config 5 on one GPU under `sharded_config`')
@@ -1253,6 +1306,8 @@ def main():
                 sh = run_sharded(sec_args, 'c5', steps=min(args.steps, 3), warmup=1)
                 if out is not None and sh is not None:
                     out['sharded_config'] = pick(sh)
+                    if world == 1:                                # what 2 / 4 / 8 ranks should take from this 1-GPU point (one xGMI link x 0.8 assumed)
+                        out['predicted'] = prediction(sh, None, (2, 4, 8))
             except Exception as e:                                # noqa: BLE001 -- reported, not swallowed
                 msg = f'{type(e).__name__}: {e}'
                 if use_pg:
@@ -1271,6 +1326,8 @@ def main():
     # the ONE line goes out before anything that can still block (a peer that died after its last collective would otherwise
     # leave rank 0 in the final barrier with the result unprinted)
     if out is not None:
+        if os.environ.get('GPK_BENCH_STUBS'):
+            out['data'] = 'STUBBED (GPK_BENCH_STUBS): not a measurement'
         emit(out)
         if bad:
             print(f'bench.py: PARITY FAILURE -- device iterate further than {PARITY_TOL:g} (relative) from the CPU oracle in: {", ".join(bad)}',

@@ -12,19 +12,24 @@ Pure Python, no GPU, no numpy: importable anywhere.
 import json
 import math
 
-LINE_TARGET = 5600
+LINE_TARGET = 6300
 LINE_CAP = 7000                     # the driver's stdout tail is 8 KB: leave room for a trailing newline and whatever precedes the line
 
 CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
             'dtype', 'data')
 SECONDARY = ('n10k', 'c3', 'c4', 'sharded_config', 'one_gpu_same_job', 'replicas_c2')
 # what goes first when the line is over LINE_TARGET (least important first); the contract, roofline, cpu_baseline and parity never go
-DROP_ORDER = ('structured_step', 'roofline_cholesky_theta', 'step_executed', 'one_time_ms', 'roofline_syrk', 'roofline_assembly',
+DROP_ORDER = ('structured_step', 'predicted', 'roofline_cholesky_theta', 'step_executed', 'one_time_ms', 'roofline_syrk', 'roofline_assembly',
               'mode_probe', 'preflight', 'replicas_c2', 'one_gpu_same_job', 'phases_ms')
 
 
 def sig(x, n=6):
     """floats to n significant digits (a 17-digit double costs 10 more bytes than the line needs); everything else unchanged"""
+    if hasattr(x, 'item') and not isinstance(x, (str, bytes)) and getattr(x, 'ndim', 0) == 0:
+        try:
+            x = x.item()            # numpy / torch scalars copied through from mode_probe, preflight, ...: plain Python numbers
+        except Exception:           # noqa: BLE001
+            pass
     if isinstance(x, bool) or not isinstance(x, float):
         return x
     if not math.isfinite(x):
@@ -137,8 +142,47 @@ def compact_secondary(o):
     return {k: v for k, v in out.items() if v not in (None, {}, '')}
 
 
+def compact_predicted(p):
+    """{P: {chol: [look-ahead, sequential], xchg: [all-gather padded, broadcasts exact], hb: [replicated, panel-sharded], step, x}} in ms"""
+    if 'error' in p:
+        return {'error': short(p['error'], 120)}
+    r1 = lambda v: round(v, 1) if isinstance(v, float) else v
+    out = {'fabric_gbs': r1(((p.get('inputs') or {}).get('fabric') or {}).get('bcast_gbs')),
+           'keys': 'chol=[lookahead,sequential] xchg=[allgather_padded,bcasts_exact] hb=[replicated,sharded] ms'}
+    for k, v in p.items():
+        if k == 'inputs' or not isinstance(v, dict):
+            continue
+        out[k] = {'chol': [r1(v['cholesky_theta_ms']['lookahead']), r1(v['cholesky_theta_ms']['sequential'])],
+                  'xchg': [r1(x) for x in v['exchange_of_S_ms'].values()],
+                  'hb': [r1(v['cholesky_of_Hb_ms']['replicated']), r1(v['cholesky_of_Hb_ms']['panel_sharded'])],
+                  'step': r1(v['step_ms_best']), 'x': round(v['predicted_vs_1gpu'], 2)}
+    return out
+
+
+def _dumps(obj):
+    return json.dumps(obj, separators=(',', ':'), default=str)      # (default=str: whatever is not JSON goes out as text, never an exception)
+
+
+def minimal(full):
+    """the contract fields alone: what goes out when compact() itself fails (the ONE stdout line must survive anything)"""
+    out = {k: sig(full.get(k)) if isinstance(full, dict) else None for k in CONTRACT}
+    if isinstance(full, dict):
+        out['value_workload'] = full.get('value_workload')
+        out['config'] = {'workload': short(str((full.get('config') or {}).get('workload', '')), 112)}
+    return _dumps(out)
+
+
 def compact(full, detail_path='bench_detail.json'):
     """the driver's line from the full result object"""
+    try:
+        return _compact(full, detail_path)
+    except Exception as e:                                          # noqa: BLE001 -- reported in the line
+        out = json.loads(minimal(full))
+        out['compact_error'] = short(f'{type(e).__name__}: {e}', 160)
+        return _dumps(out)
+
+
+def _compact(full, detail_path):
     out = {k: full.get(k) for k in CONTRACT}
     out['value_workload'] = full.get('value_workload')
     out['config'] = compact_config(full.get('config'), True)
@@ -170,9 +214,13 @@ def compact(full, detail_path='bench_detail.json'):
         out['preflight'] = full['preflight']
     if 'fallback' in full:
         out['fallback'] = short(full['fallback'], 200)
+    if isinstance(full.get('predicted'), dict):                     # bench_model.table: per rank count, [a, b] pairs in ms, one decimal
+        out['predicted'] = compact_predicted(full['predicted'])
+    if 'predicted_vs_1gpu' in full:
+        out['predicted_vs_1gpu'] = full['predicted_vs_1gpu']
     out['detail'] = detail_path
     out = rounded(out)
-    line = json.dumps(out, separators=(',', ':'))
+    line = _dumps(out)
     dropped = []
     for k in DROP_ORDER:                                            # over the target: shed the least important objects, say which
         if len(line) <= LINE_TARGET:
@@ -181,15 +229,15 @@ def compact(full, detail_path='bench_detail.json'):
             del out[k]
             dropped.append(k)
             out['dropped_for_size'] = dropped
-            line = json.dumps(out, separators=(',', ':'))
+            line = _dumps(out)
     for k in SECONDARY:                                             # still over the hard cap (cannot happen with the objects above): numbers only
         if len(line) <= LINE_CAP:
             break
         if isinstance(out.get(k), dict):
             out[k] = pick(out[k], ('value', 'ms_per_step', 'error'))
-            line = json.dumps(out, separators=(',', ':'))
+            line = _dumps(out)
     if len(line) > LINE_CAP:
         out = {k: out.get(k) for k in CONTRACT + ('value_workload', 'roofline', 'cpu_baseline', 'parity', 'detail')}
         out['config'] = {'workload': short(str((full.get('config') or {}).get('workload', '')), 112)}
-        line = json.dumps(out, separators=(',', ':'))
+        line = _dumps(out)
     return line

@@ -176,7 +176,9 @@ int gpk_gn_dims(const gpk_gn_problem* host_prob, int* nz, int* s_rows);
  * handle will reserve by itself.  lds: the leading dimension the caller intends to use for S and Hb (0 = the smallest admissible one,
  * nz + 1 rounded up to 16 doubles; returned in *host_lds).  *S_bytes = s_rows * lds * 8, *Hb_bytes = (nz + 1) * lds * 8, *delta_bytes =
  * nz * 8, *handle_bytes = the out-of-place solve buffer the handle grows on first use when the inverted diagonal blocks of EVERY factor are
- * supplied (s_rows * lds * 8 -- whatever dinv_block says, 0 meaning 256 -- else 0; + s_rows * 8 for the exact in-step loss).  Any output pointer may be NULL. */
+ * supplied (s_rows * lds * 8 -- whatever dinv_block says, 0 meaning 256 -- else 0; + s_rows * 8 for the exact in-step loss).  An UPPER
+ * BOUND on the large buffers (the loss vector is counted whether or not gpk_tune key 52 is on); on top of it the handle keeps two sets
+ * of hand-off records of its single-vector solves (2 x 4 MB, fixed) once the in-step loss runs on its side stream.  Any output pointer may be NULL. */
 int gpk_gn_worksize(const gpk_gn_problem* host_prob, int lds, int* host_lds, size_t* S_bytes, size_t* Hb_bytes, size_t* delta_bytes,
                     size_t* handle_bytes);
 /* (With host_prob->Dinv set, S is scratch and the solved block lives in the handle's workspace.) */
@@ -185,10 +187,15 @@ int gpk_gn_worksize(const gpk_gn_problem* host_prob, int lds, int* host_lds, siz
  *   S  = [L^{-1}A(z) | L^{-1}F(z)]                (s_rows x (nz+1), ld lds)
  *   Hb = S^T S  (bordered: H/2, g/2, loss)        ((nz+1) x (nz+1), ld ldh)
  *   z <- z - step * H^{-1} g                       via Cholesky of Hb
- * host_loss_in = loss(z_in) = sum_k ||L_k^{-1} F_k(z_in)||^2 by TRUE SUBSTITUTION with the factor(s) (round 5: one vector, solved in front
- * of the solve phase; exact to rounding like gpk_gn_loss -- rounds 2-4 returned the squared norm
- * of the F column of the GEMM-only solve instead, ~1e-8 relative error at nugget <= 1e-12 near convergence; the structured modes below
- * report their own form of it); host_info = potrf info of H (0 ok).  delta (nz,) receives H^{-1} g.  One call = one iteration of the
+ * host_loss_in = loss(z_in) = sum_k ||L_k^{-1} F_k(z_in)||^2 by TRUE SUBSTITUTION with the factor(s) (one vector; exact to rounding like
+ * gpk_gn_loss -- rounds 2-4 returned the squared norm of the F column of the GEMM-only solve instead, ~1e-8 relative error at nugget
+ * <= 1e-12 near convergence; since round 6 the structured modes below report the substituted value as well).  WHERE it runs: F(z_in) is
+ * written at the start of the call on the handle's stream; from the second call of a handle on, the substitution chain (one single-vector
+ * solve per factor + a dot product) is issued on an INTERNAL side stream of the handle (the CU-masked stream of the pipelined phase),
+ * next to the end of the step, and joined before the call returns -- the call is still synchronous for the caller and ordered on the
+ * handle's stream, but a profiler shows a second stream; the first call of a handle, handles without the two-partition pipeline and
+ * gpk_tune(h, 52, 2) run the chain on the handle's stream in front of the solve phase.  host_info = potrf info of H (0 ok).
+ * delta (nz,) receives H^{-1} g.  One call = one iteration of the
  * reference's GN_method loop (Hessian, gradient, solve, update, one loss evaluation). */
 int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double step_size,
                 double* S, int lds, double* Hb, int ldh, double* delta, double* host_loss_in, int* host_info);

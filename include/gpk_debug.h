@@ -19,8 +19,9 @@ extern "C" {
  * key 10 = 0: substitution strips even when Dinv is given; key 12 = 0: SYRK then right-looking Cholesky on one stream instead of the
  * two-partition pipeline; key 13 = CUs of the chain partition (default 32); key 23 = 0: dense schedule for the Eikonal, Burgers and
  * Darcy systems; key 24 = workgroups per split-K product launch of the pipeline (default 1000, 0 = no split); key 52 = the loss
- * gpk_gn_step reports (1, default: true substitution, one vector, in front of the solve phase; 0: the approximate number taken from the F
- * column of the GEMM-only solve, rounds 2-4).
+ * gpk_gn_step reports (1, default: true substitution, one vector, its chain on the handle's internal side stream next to the end of the
+ * step -- include/gpk.h, gpk_gn_step; 2: the same chain on the handle's stream in front of the solve phase; 0: the approximate number
+ * taken from the F column of the GEMM-only solve, rounds 2-4).
  * No process-wide state (round 4): handles of one process can run different variants side by side.  Unknown key: error. */
 int gpk_tune(gpk_handle h, int key, int value);
 #ifdef __cplusplus

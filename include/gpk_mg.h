@@ -59,8 +59,10 @@ int gpk_mg_rccl_unique_id(const char* librccl_path, void* host_id128);
 int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* host_id128);
 /* key 0: look-ahead (0 off, 1 on; default on for world > 1);  key 1: Cholesky of Hb (0 replicated, 1 panel-sharded;
  * default sharded for world >= 4);  key 2: alignment of the column shards of the step (default 128);
- * key 3: exchange of the column shards of S in the step (0 = one all-gather, default; 1 = one broadcast per shard on the
- * communication stream, the block-row products of Hb issued behind the arrival of the shards they read) */
+ * key 3: exchange of the column shards of S in the step (0 = one all-gather, every shard padded to the widest; 1 = one broadcast
+ * per shard, exact sizes, on the communication stream, the block-row products of Hb issued behind the arrival of the shards they
+ * read; -1 = default: the form that puts fewer bytes on a link -- broadcasts when (world - 1) x widest shard > all columns, which
+ * holds from 4 ranks on for the work-balanced shards of BASELINE config 5 (widest / mean 1.57 at 4 ranks, 1.79 at 8)) */
 int gpk_mg_set_option(gpk_mg_handle mg, int key, int value);
 
 /* Health check of the bound collectives (every rank calls it): a broadcast from rank 0 and an all-gather of small buffers,

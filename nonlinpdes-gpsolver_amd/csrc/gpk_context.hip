@@ -106,7 +106,10 @@ extern "C" int gpk_device_info(gpk_handle h, char* name, int name_len, int* cus,
     if (!h) return GPK_ERR_ARG;
     hipDeviceProp_t prop;
     GPK_HIP(h, hipGetDeviceProperties(&prop, h->device));
-    if (name && name_len > 0) { snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName); }
+    if (name && name_len > 0) {                       // (prop.name is EMPTY on some boxes of the pool: the architecture string alone then)
+        if (prop.name[0]) snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+        else snprintf(name, name_len, "%s", prop.gcnArchName);
+    }
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm) *hbm = prop.totalGlobalMem;
     if (clock_khz) *clock_khz = prop.clockRate;

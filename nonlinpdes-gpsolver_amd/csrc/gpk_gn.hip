@@ -263,8 +263,17 @@ int exact_loss_build(gpk_handle h, const gpk_gn_problem* p, const Dims& d, const
 
 // after_main: the phase before the tail ran on the main stream (no two-partition pipeline): the chain waits for it; otherwise it only waits
 // for F(z) and queues behind the GEMM partition's own last launch of the pipelined phase
-int exact_loss_chain(gpk_handle h, const Dims& d, bool after_main) {
+int exact_loss_chain(gpk_handle h, const Dims& d, bool after_main, bool* on_side) {
     const hipStream_t main_s = h->stream, side = h->pipe_g;
+    *on_side = false;
+    if (!side || h->pipe_unavailable) {
+        // the side stream went away between the decision at the start of the step and here (the pipelined phase re-created its streams and
+        // failed: gpk_i_syrk_potrf, gpk_tune key 13): F(z) is in d_loss_work already, finish on the main stream -- never on the NULL stream
+        for (int k = 0; k < d.ngroups; ++k)
+            if (d.g[k].L) GPK_TRY(gpk_i_trsv(h, false, d.g[k].L, d.g[k].n, d.g[k].ldl, h->d_loss_work + d.g[k].off));
+        return gpk_i_dot(h, h->d_loss_work, h->d_loss_work, d.rows, h->d_scalars + 8);
+    }
+    *on_side = true;
     if (after_main) GPK_HIP(h, hipEventRecord(h->ev_loss[0], main_s));
     GPK_HIP(h, hipStreamWaitEvent(side, h->ev_loss[0], 0));
     h->stream = side; h->trsv_alt = 1;
@@ -599,6 +608,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         GPK_TRY(gpk_i_dot(h, coef + 5 * nz, coef + 5 * nz, d.rows, d_loss));
         h->pipe_tev_used = 0; h->prof_pipelined = 0;
         GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));
+        // the REPORTED loss by true substitution here too (round 6; the class API takes its history from this number): one vector on
+        // the main stream behind the factorisation -- the level's own d_loss (above) stays the corner of Hb
+        if (h->tune.exact_loss) { exact = true; GPK_TRY(exact_loss(h, p, d, z)); }
     } else if (h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->W1 && p->W2 && p->v0 && p->ldw >= nz + 1) {
         // optional structured solve (gpk_gn_structured_prepare): one memory-bound pass over W1, W2 instead of the triangular solve
         GPK_PROF_MARK(h, 0);
@@ -608,6 +620,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         structured_coeff_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(nz, p->p0, p->p1, z, coef, coef + nz, coef + 2 * nz);
         structured_form_kernel<<<d.rows, 256, 0, h->stream>>>(nz, p->W1, p->W2, p->ldw, p->v0, coef, coef + nz, coef + 2 * nz, W, lds);
         GPK_LAUNCH_CHECK(h);
+        if (h->tune.exact_loss) { exact = true; GPK_TRY(exact_loss(h, p, d, z)); }   // reported loss: true substitution (round 6), as in the plain branch
         GPK_PROF_MARK(h, 1);
     } else {
         // the loss of the iterate this step starts from, exact (true substitution with the factors, one vector), in front of the solve
@@ -652,7 +665,17 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     GPK_PROF_MARK(h, 3);
     // the chain of the exact loss: on the GEMM partition's stream from here on (pipelined phase: that stream's last product finished before the
     // last panel chain did, so it starts early; otherwise behind the factorisation just issued), next to the tail below
-    if (exact_late) GPK_TRY(exact_loss_chain(h, d, !h->prof_pipelined));
+    // (any error return from here to the end of the call first drains the side stream: the next call's exact_loss_build memsets d_loss_work
+    // on the main stream, which must not happen under a chain that is still reading it)
+    struct ChainGuard {
+        gpk_handle h; bool armed;
+        ~ChainGuard() { if (armed && h->pipe_g) (void)hipStreamSynchronize(h->pipe_g); }
+    } chain_guard{h, false};
+    bool chain_on_side = false;
+    if (exact_late) {
+        GPK_TRY(exact_loss_chain(h, d, !h->prof_pipelined, &chain_on_side));
+        chain_guard.armed = chain_on_side;
+    }
     double* dl = rev ? S : delta;                                    // scratch for the (reversed-order) solution: S is free now
     GPK_HIP(h, hipMemcpyAsync(dl, Hb + (long)nz * ldh, (size_t)nz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     GPK_TRY(gpk_i_trsv(h, true, Hb, nz, ldh, dl));
@@ -666,9 +689,10 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     GPK_PROF_MARK(h, 4);
     // the two host scalars of the step through pinned memory (h_pinned[0] = loss, the int behind h_pinned[1] = pivot status)
     GPK_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    if (exact_late) GPK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_loss[1], 0));
+    if (chain_on_side) GPK_HIP(h, hipStreamWaitEvent(h->stream, h->ev_loss[1], 0));
     GPK_HIP(h, hipMemcpyAsync(h->h_pinned, exact ? h->d_scalars + 8 : d_loss, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
+    chain_guard.armed = false;                                       // the main stream waited for the chain's event: it is complete
     int info = *reinterpret_cast<const int*>(h->h_pinned + 1);
     const double loss = h->h_pinned[0];
     if (h->prof) {

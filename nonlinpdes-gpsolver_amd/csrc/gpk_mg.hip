@@ -21,8 +21,11 @@ struct gpk_mg_ctx {
     gpk_handle h = nullptr;
     int rank = 0, world = 1, nb = 512;
     int lookahead = 0, shard_hb = 0, col_align = 128;
-    int overlap_s = 0;                     // step: 0 = one all-gather of the column shards of S, 1 = one broadcast per shard on the communication
-                                           // stream with the block-row products of Hb chasing the arrivals (gpk_mg_set_option key 3)
+    int overlap_s = -1;                    // step: 0 = one all-gather of the column shards of S (padded to the widest), 1 = one broadcast per shard
+                                           // (exact sizes) on the communication stream with the block-row products of Hb chasing the arrivals,
+                                           // -1 (default) = by the bytes each form puts on a link: the shards are cut by WORK, so their widths
+                                           // differ (widest / mean = 1.30 / 1.57 / 1.79 at 2 / 4 / 8 ranks of config 5) and the all-gather moves
+                                           // (P - 1) x widest columns per rank against nc columns for the broadcasts (gpk_mg_set_option key 3)
     void* comm = nullptr;
     gpk_mg_bcast_fn bcast = nullptr;
     gpk_mg_allgather_fn allgather = nullptr;
@@ -368,7 +371,7 @@ extern "C" int gpk_mg_set_option(gpk_mg_handle mg, int key, int value) {
     if (key == 0) { mg->lookahead = value != 0; return 0; }
     if (key == 1) { mg->shard_hb = value != 0; return 0; }
     if (key == 2 && value >= 1) { mg->col_align = value; return 0; }
-    if (key == 3) { mg->overlap_s = value != 0; return 0; }
+    if (key == 3 && value >= -1 && value <= 1) { mg->overlap_s = value; return 0; }
     return gpk_bad_arg(mg->h, "gpk_mg_set_option: key / value");
 }
 
@@ -559,22 +562,23 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     //         columns [0, i0 + ib), i.e. the shards up to the one that holds its last column -- its product is issued behind that
     //         shard's event, so the early block rows are computed while the later shards are still travelling.
     const size_t shard = (size_t)rows * per;
+    const bool overlap_s = mg->overlap_s < 0 ? (long)(P - 1) * per > (long)nc : mg->overlap_s != 0;   // (a function of the shapes: all ranks agree)
     const int nblk = gpk_ceil_div(nc, nb), per_rank = gpk_ceil_div(nblk, P);
     // the block rows travel as their LOWER parts only (round 4): block row i is ib x (i0 + ib); every rank's share padded to the largest
     std::vector<size_t> share((size_t)P, 0);
     for (int i = 0; i < nblk; ++i) { const int i0 = i * nb, ib = std::min(nb, nc - i0); share[i % P] += (size_t)ib * (size_t)(i0 + ib); }
     const size_t hshare = *std::max_element(share.begin(), share.end());
     (void)per_rank;
-    const size_t all_s = mg->overlap_s ? (size_t)rows * nc : shard * P;
+    const size_t all_s = overlap_s ? (size_t)rows * nc : shard * P;
     GPK_TRY(ensure_gather(mg, std::max(shard, hshare) * sizeof(double), std::max(all_s, hshare * P) * sizeof(double)));
     if (c1 > c0)
-        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)(mg->overlap_s ? c1 - c0 : per) * 8, S2 + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)rows,
+        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)(overlap_s ? c1 - c0 : per) * 8, S2 + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)rows,
                                     hipMemcpyDeviceToDevice, s));
     auto block_row = [&](int i) {
         const int i0 = i * nb, ib = std::min(nb, nc - i0);
         return gpk_i_gemm(h, true, false, ib, i0 + ib, rows, 1.0, S2 + i0, lds, S2, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, nz);
     };
-    if (!mg->overlap_s) {
+    if (!overlap_s) {
         MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, shard, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of S");
         for (int r = 0; r < P; ++r) {
             const int a0 = b[r], a1 = b[r + 1];

@@ -11,8 +11,8 @@ def _vec(fun, x1, x2):
         out = onp.asarray(fun(x1, x2), dtype=float)
         if out.shape == onp.broadcast(x1, x2).shape:
             return out
-    except Exception:
-        pass
+    except (TypeError, ValueError):                   # a scalar-only callback (math.sin, float(...)): evaluated point by point below;
+        pass                                          # anything else the callback raises is the caller's bug and propagates
     return onp.vectorize(lambda a, b: float(fun(a, b)))(x1, x2)
 
 

@@ -162,7 +162,18 @@ class _GPEquation(object):
             return random.normal(0.0, 1.0, (n))
         raise UnboundLocalError("local variable 'sol' referenced before assignment")   # as the reference
 
+    def _check_step_info(self, it, info):
+        """info > 0: the Cholesky of the Gauss-Newton matrix H of step `it` met a non-positive pivot (LAPACK numbering).  The reference
+        solves H with jnp.linalg.solve (src/PDEs.py:118), which never reports anything and carries on with whatever comes out; here the step
+        has been taken with NaNs from that pivot on, exactly as visible in the next loss -- say so at once, in the reference's wording."""
+        self.step_info = getattr(self, 'step_info', [])
+        self.step_info.append(int(info))
+        if info > 0:
+            print('[Error] Cholesky factorization of the Gauss-Newton matrix failed at step', it, '(non-positive pivot at index', info,
+                  '): maybe nugget is too small!')
+
     def _gn_iterate(self, prob, sol, max_iter, step_size, print_hist, check_nan=True):
+        self.step_info = []
         ctx = get_context()
         z = ctx.array(sol)
         loss_hist = []
@@ -177,20 +188,22 @@ class _GPEquation(object):
                 else:
                     print('iter = ', it, 'Gauss-Newton step size =', step_size, ' Loss = ', value)
         # The loss history is the reference's: J(z_0), then J(z_k) after every update (src/PDEs.py:108-124).  gpk_gn_step returns the
-        # loss of the iterate it STARTS from -- since round 5 by true substitution with the factor (one vector, solved in front of the
-        # solve phase: exact to rounding, like gpk_gn_loss) -- so max_iter steps yield
+        # loss of the iterate it STARTS from -- since round 5 by true substitution with the factor (one vector; its chain runs on the handle's side
+        # stream beside the end of the step: exact to rounding, like gpk_gn_loss; round 6: in the structured modes too) -- so max_iter steps yield
         # J(z_0) .. J(z_{max_iter-1}) and one gpk_gn_loss closes the history.  Rounds 2-4 took that number from the F column of the
         # GEMM-only solve (~1e-8 relative error at nugget <= 1e-12 near convergence: gpk_tune(52, 0)) and round 4 therefore called
         # gpk_gn_loss after every step; GPK_SEPARATE_LOSS=1 keeps that sequence (same numbers to rounding, one more solve per step).
         if os.environ.get('GPK_SEPARATE_LOSS', '0') != '1':
             for it in range(max_iter):
-                loss_in, _info = ctx.gn_step(prob, z, step_size)  # loss of the iterate the step starts from
+                loss_in, info = ctx.gn_step(prob, z, step_size)   # loss of the iterate the step starts from
                 record(it, loss_in)
+                self._check_step_info(it + 1, info)
             record(max_iter, ctx.gn_loss(prob, z))
         else:
             record(0, ctx.gn_loss(prob, z))
             for it in range(1, max_iter + 1):
-                ctx.gn_step(prob, z, step_size)
+                _, info = ctx.gn_step(prob, z, step_size)
+                self._check_step_info(it, info)
                 record(it, ctx.gn_loss(prob, z))
         self.max_iter = max_iter
         self.step_size = step_size

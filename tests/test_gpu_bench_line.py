@@ -79,3 +79,18 @@ def test_config1_line_has_the_contract_fields_and_parity():
     assert fc['solve_launches_per_step'] == r['launches_per_step']
     assert fc['product_flops_per_step'] == pytest.approx(d['roofline_syrk']['launched_flops_per_step'], rel=1e-12)
     assert d['l2_error']['pts_L2_err'] < 1e-6 and d['l2_error']['test_L2_err'] < 1e-6
+
+
+def test_bare_two_rank_command_on_one_gpu():
+    """`python3 bench.py --gpus 2 --steps 1 --warmup 0` with NOTHING around it (round 6: bench.py starts its own ranks, bench_launch.py) --
+    on this 1-GPU box both ranks share the device (process group over gloo, the bound collectives staged through the host:
+    GPK_BENCH_BACKEND=gloo GPK_BENCH_COMM=staged).  The line is the N > 1 line: `value` = the sharded BASELINE config 5 with the real
+    kernels, the same job's 1-GPU point beside it, the preflight of the bound collectives."""
+    d, full, out = _run('--gpus', '2', '--steps', '1', '--warmup', '0', '--no-replicas',
+                        env_extra={'GPK_BENCH_BACKEND': 'gloo', 'GPK_BENCH_COMM': 'staged', 'GPK_SHARDED_TIMEOUT': '1200'})
+    assert d['n_gpus'] == 2 and d['value_workload'] == 'c5' and d['scaling'] == 'strong' and d['data'] == 'synthetic'
+    assert d['value'] > 0 and abs(d['value'] * d['ms_per_step'] / 1e3 - 1.0) < 1e-4
+    assert d['one_gpu_same_job']['value'] > 0 and d['vs_1gpu'] == pytest.approx(d['value'] / d['one_gpu_same_job']['value'], rel=1e-4)
+    assert d['preflight']['ranks_seen_by_rccl'] == 2
+    assert d['l2_error']['pts_L2_err'] < 1e-6 and d['parity_failed'] is None
+    assert isinstance(d.get('predicted'), dict) or isinstance(full.get('predicted'), dict)      # the host model beside the measurement
