@@ -136,6 +136,10 @@ def compact_secondary(o):
         out['parity'].pop('tol', None)
     if isinstance(o.get('mode_probe'), dict):
         out['mode_probe'] = pick(o['mode_probe'], ('lookahead_kept', 'shard_hb_kept', 'overlap_s_kept'))
+    st = o.get('structured_step')
+    if isinstance(st, dict):                                        # optional structured solve of this workload: ms, one-time cost, agreement
+        lv = st.get('solve_level')
+        out['structured'] = pick(lv, ('ms_per_step', 'setup_ms', 'iterate_rel_diff_vs_default')) if isinstance(lv, dict) else {'error': short(str(st.get('error')), 120)}
     for k in ('error', 'fallback'):
         if k in o:
             out[k] = short(o[k], 160)

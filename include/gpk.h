@@ -164,10 +164,12 @@ typedef struct {
     const double* Dinv;            /* optional (may be NULL): gpk_trtri_diag(L)  -- the S solve then runs as GEMMs only */
     const double* Dinv2;           /* optional, DARCY: gpk_trtri_diag(L2) */
     int dinv_block;                /* block size Dinv / Dinv2 were built with (0 = 256) */
-    /* optional (may be NULL), GPK_GN_ELLIPTIC only -- see gpk_gn_structured_prepare */
+    /* optional (may be NULL) -- see gpk_gn_structured_prepare (v0: GPK_GN_ELLIPTIC only) */
     const double* W1; const double* W2; const double* v0; int ldw;
     /* optional (may be NULL), needs W1/W2/v0 -- see gpk_gn_gram_prepare */
     const double* G; int ldg; const double* pvec;
+    /* optional (may be NULL), GPK_GN_DARCY only -- see gpk_gn_darcy_prepare */
+    const double* Wa; int ldwa; const double* Ha; int ldha;
 } gpk_gn_problem;
 
 /* sizes: nz unknowns, rows of the stacked S = [L^{-1}A | L^{-1}F] buffer */
@@ -205,7 +207,15 @@ int gpk_gn_step(gpk_handle h, const gpk_gn_problem* host_prob, double* z, double
  *   gpk_gn_step),  v0 = L^{-1} F(0)  (s_rows)
  * computed ONCE by this call (two solves; S is scratch, s_rows x lds), every later gpk_gn_step whose host_prob carries W1, W2, v0, ldw
  * forms  S = [W1 diag(d(z)) + W2 | v0 + W1 (alpha z^m) + W2 z]  in one memory-bound pass instead of the triangular solve.  Same
- * iterates up to rounding (tests/test_gpu_structured.py); the product, the factorisation and the update are unchanged. */
+ * iterates up to rounding (tests/test_gpu_structured.py); the product, the factorisation and the update are unchanged.
+ * Systems other than the elliptic one (round 6: GPK_GN_BURGERS, GPK_GN_EIKONAL, GPK_GN_DARCY; needs Dinv / Dinv2 / dinv_block, i.e. the
+ * GEMM-only solve path and its leading-zero layout).  Every column of their A(z) has at most ONE entry that depends on z -- Burgers:
+ * the PDE row (-alpha v2, -alpha v0, nu: src/PDEs.py:297-299 of the reference), Eikonal: 2 v1 / eps, 2 v2 / eps (:443-445), Darcy: the
+ * v3 row of the u-part (f e^{-w0}, -v1, -v2, -w1, -w2: src/InverseProblems.py:131-135) -- so A(z) = A1 diag(d(z)) + A2 with constant
+ * 0/1 patterns, and  W1 = L^{-1} A1,  W2 = L^{-1} A2  (all row groups stacked, s_rows x (nz+1) each, ldw even and >= nz+1; v0 is not
+ * used and may be NULL) are computed ONCE here.  Every later gpk_gn_step whose host_prob carries W1, W2, ldw forms
+ * L^{-1}A(z) = W1 diag(d(z)) + W2 in one memory-bound pass; the column L^{-1}F(z) is still SOLVED every step (one column per factor).
+ * Same iterates up to rounding (tests/test_gpu_structured.py: <= 1e-8 relative to the per-step solve, <= 1e-6 to the oracle). */
 int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* S, int lds, double* W1, double* W2, double* v0, int ldw);
 /* OPTIONAL second level of the structured mode (elliptic system): with the Gram blocks of W = [W1 W2],
  *   G = [G11; G12; G21; G22]  (four nz x nz blocks stacked, leading dimension ldg >= nz; Gij = Wi^T Wj),
@@ -216,6 +226,18 @@ int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* host_prob, dou
  * in O(nz^2) memory-bound work per step: neither the triangular solve nor the product S^T S is executed; the Cholesky
  * factorisation of H, the solve and the update are unchanged.  Same iterates up to rounding (tests/test_gpu_structured.py). */
 int gpk_gn_gram_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* G, int ldg, double* pvec);
+/* Darcy system: the iteration-independent part of the step, computed ONCE per factor (round 6).  The a-part rows of GN_loss,
+ * [w1; w2; w0] against L_a (src/InverseProblems.py:137-146 of the reference), do not involve z_old: their block of A(z) is a
+ * permutation matrix, so W_a = L_a^{-1} A_a and its contribution H_a = W_a^T W_a to the Gauss-Newton matrix are the same in every
+ * step -- the reference recomputes them inside every Hessian_GN because autodiff cannot know.  This call runs exactly the launches a
+ * step would (same kernels, same shapes) and keeps their results:
+ *   Wa (3 N_d x 3 N_d, ld ldwa >= 3 N_d): the solved a-part block in the step's internal column order; must not alias S;
+ *   Ha (3 N_d x 3 N_d, ld ldha >= 3 N_d): the lower triangle of W_a^T W_a;
+ * S (s_rows x lds) is scratch.  A gpk_gn_step whose host_prob carries Wa/ldwa/Ha/ldha then skips the a-part's 3 N_d-column solve and
+ * its product (an O(N_d^2) add instead); the a-part's F column (which depends on z) is still solved every step.  The iterates are
+ * BIT-IDENTICAL to the uncached step (tests/test_gpu_structured.py).  Needs Dinv / Dinv2 (the GEMM-only solve path); on the other
+ * paths the fields are ignored.  The caller must drop Wa / Ha when L2 is refactored. */
+int gpk_gn_darcy_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* S, int lds, double* Wa, int ldwa, double* Ha, int ldha);
 /* building blocks of gpk_gn_step for the column-sharded multi-GPU step: S <- [A(z) | F(z)] (no solve), y += alpha x */
 int gpk_gn_build(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* S, int lds);
 /* Same with unknown j stored in column n_z-1-j (elliptic system only): column c < n_z of [A | F] is then zero above row

@@ -102,29 +102,37 @@ __device__ __forceinline__ void store_row(const AsmArgs& g, int p, int q, const 
 // be even multiples of 8 bytes (checked by the launcher; otherwise the one-point-per-lane kernel below runs).
 typedef double asm_d2 __attribute__((ext_vector_type(2)));
 
-template <int L, int BI, int BJ>
+template <int L, int BI, int BJ, int NT>
 __device__ __forceinline__ void store_block2(const AsmArgs& g, int p, int q, const double (&a0)[5], const double (&b0)[5], double e0,
                                              const double (&a1)[5], const double (&b1)[5], double e1) {
     if (q < g.size[BJ]) {                                            // (sizes are even here: q and q + 1 are both inside or both outside)
         double v0 = pair_coeff<Lay<L>::f[BI], Lay<L>::f[BJ]>(a0, b0) * e0;
         double v1 = pair_coeff<Lay<L>::f[BI], Lay<L>::f[BJ]>(a1, b1) * e1;
         if (BI == BJ) { if (p == q) v0 += g.nug[BI]; if (p == q + 1) v1 += g.nug[BI]; }
-        *reinterpret_cast<asm_d2*>(g.out + (long)(g.off[BI] + p) * g.ld + g.off[BJ] + q) = (asm_d2){v0, v1};
+        asm_d2* dst = reinterpret_cast<asm_d2*>(g.out + (long)(g.off[BI] + p) * g.ld + g.off[BJ] + q);
+        // NT (gpk_tune key 55): Theta is written once and not read by this kernel -- a non-temporal store (global_store_dwordx4 ... nt)
+        // tells L2 / the Infinity Cache not to keep the line
+        // (2 / 3: write-through scopes sc0 sc1 without / with nt, inline asm -- measured next to it, see the table at gpk_assemble below)
+        const asm_d2 v = (asm_d2){v0, v1};
+        if (NT == 1) __builtin_nontemporal_store(v, dst);
+        else if (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(v) : "memory");
+        else if (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(dst), "v"(v) : "memory");
+        else *dst = v;
     }
 }
 
-template <int L, int BI>
+template <int L, int BI, int NT>
 __device__ __forceinline__ void store_row2(const AsmArgs& g, int p, int q, const double (&a0)[5], const double (&b0)[5], double e0,
                                            const double (&a1)[5], const double (&b1)[5], double e1) {
     if (p < g.size[BI]) {                               // wave-uniform
-        store_block2<L, BI, 0>(g, p, q, a0, b0, e0, a1, b1, e1);
-        if (Lay<L>::nb > 1) store_block2<L, BI, 1>(g, p, q, a0, b0, e0, a1, b1, e1);
-        if (Lay<L>::nb > 2) store_block2<L, BI, 2>(g, p, q, a0, b0, e0, a1, b1, e1);
-        if (Lay<L>::nb > 3) store_block2<L, BI, 3>(g, p, q, a0, b0, e0, a1, b1, e1);
+        store_block2<L, BI, 0, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 1) store_block2<L, BI, 1, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 2) store_block2<L, BI, 2, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 3) store_block2<L, BI, 3, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
     }
 }
 
-template <int L>
+template <int L, int NT>
 __global__ __launch_bounds__(256) void assemble2_kernel(AsmArgs g) {
     const int q = 2 * (blockIdx.x * 256 + threadIdx.x);
     const bool live = q < g.M;                                       // (M even: q + 1 < M as well)
@@ -141,10 +149,10 @@ __global__ __launch_bounds__(256) void assemble2_kernel(AsmArgs g) {
         double a0[5], b0[5], a1[5], b1[5];
         hermite(g.p1, d1a, a0); hermite(g.p2, d2a, b0);
         hermite(g.p1, d1b, a1); hermite(g.p2, d2b, b1);
-        store_row2<L, 0>(g, p, q, a0, b0, e0, a1, b1, e1);
-        if (Lay<L>::nb > 1) store_row2<L, 1>(g, p, q, a0, b0, e0, a1, b1, e1);
-        if (Lay<L>::nb > 2) store_row2<L, 2>(g, p, q, a0, b0, e0, a1, b1, e1);
-        if (Lay<L>::nb > 3) store_row2<L, 3>(g, p, q, a0, b0, e0, a1, b1, e1);
+        store_row2<L, 0, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 1) store_row2<L, 1, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 2) store_row2<L, 2, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
+        if (Lay<L>::nb > 3) store_row2<L, 3, NT>(g, p, q, a0, b0, e0, a1, b1, e1);
     }
 }
 
@@ -315,11 +323,20 @@ extern "C" int gpk_assemble(gpk_handle h, int layout, int kernel, const double* 
     } asm_stop{h};
     if (pairs) {
         dim3 grid2(gpk_ceil_div(g.M / 2, 256), gpk_ceil_div(g.M, TP));
-        switch (layout) {
-            case GPK_LAYOUT_ELLIPTIC: assemble2_kernel<GPK_LAYOUT_ELLIPTIC><<<grid2, 256, 0, h->stream>>>(g); break;
-            case GPK_LAYOUT_BURGERS:  assemble2_kernel<GPK_LAYOUT_BURGERS><<<grid2, 256, 0, h->stream>>>(g); break;
-            case GPK_LAYOUT_EIKONAL:  assemble2_kernel<GPK_LAYOUT_EIKONAL><<<grid2, 256, 0, h->stream>>>(g); break;
-            case GPK_LAYOUT_DARCY_A:  assemble2_kernel<GPK_LAYOUT_DARCY_A><<<grid2, 256, 0, h->stream>>>(g); break;
+        auto launch = [&](auto nt_c) {
+            constexpr int NT = decltype(nt_c)::value;
+            switch (layout) {
+                case GPK_LAYOUT_ELLIPTIC: assemble2_kernel<GPK_LAYOUT_ELLIPTIC, NT><<<grid2, 256, 0, h->stream>>>(g); break;
+                case GPK_LAYOUT_BURGERS:  assemble2_kernel<GPK_LAYOUT_BURGERS, NT><<<grid2, 256, 0, h->stream>>>(g); break;
+                case GPK_LAYOUT_EIKONAL:  assemble2_kernel<GPK_LAYOUT_EIKONAL, NT><<<grid2, 256, 0, h->stream>>>(g); break;
+                case GPK_LAYOUT_DARCY_A:  assemble2_kernel<GPK_LAYOUT_DARCY_A, NT><<<grid2, 256, 0, h->stream>>>(g); break;
+            }
+        };
+        switch (h->tune.asm_nt) {
+            case 1: launch(std::integral_constant<int, 1>{}); break;
+            case 2: launch(std::integral_constant<int, 2>{}); break;
+            case 3: launch(std::integral_constant<int, 3>{}); break;
+            default: launch(std::integral_constant<int, 0>{}); break;
         }
         GPK_LAUNCH_CHECK(h);
         return 0;

@@ -121,6 +121,29 @@ __global__ __launch_bounds__(256) void gn_build_kernel(BuildArgs a) {
             putF(a, t, alpha * pow(zi, m) - a.f[t]);
             putF(a, Nd + t, zi);
         } else if (t < Nd + Nb) putF(a, 2 * Nd + (t - Nd), a.gb[t - Nd]);
+    } else if (a.family != 0) {
+        // gpk_gn_structured_prepare, systems other than the elliptic one (round 6).  Every column of A(z) has at most ONE entry that
+        // depends on z -- Burgers: the PDE row t (src/PDEs.py:297-299 of the reference); Eikonal: the row 2 N_d + t (:443-445); Darcy: the
+        // v3 row of the u-part (src/InverseProblems.py:131-135) -- so A(z) = A_1 diag(d(z)) + A_2 with 0/1 patterns A_1 (family 1: those
+        // entries as ones) and A_2 (family 2: the entries that are constants; Darcy's 1/gamma in the data rows included).  No F column.
+        if (t >= Nd) return;
+        if (a.system == GPK_GN_BURGERS) {
+            if (a.family == 1) { putA(a, t, t, 1.0); putA(a, t, Nd + t, 1.0); putA(a, t, 2 * Nd + t, 1.0); }
+            else { putA(a, Nd + t, Nd + t, 1.0); putA(a, 2 * Nd + t, 2 * Nd + t, 1.0); putA(a, 3 * Nd + t, t, 1.0); }
+        } else if (a.system == GPK_GN_EIKONAL) {
+            if (a.family == 1) { putA(a, 2 * Nd + t, Nd + t, 1.0); putA(a, 2 * Nd + t, 2 * Nd + t, 1.0); }
+            else { putA(a, t, Nd + t, 1.0); putA(a, Nd + t, 2 * Nd + t, 1.0); putA(a, 3 * Nd + t, t, 1.0); }
+        } else if (a.system == GPK_GN_DARCY) {
+            const int U = 3 * Nd, D = 7 * Nd + Nb;
+            if (a.family == 1) {
+                putA(a, U + 2 * Nd + t, t, 1.0); putA(a, U + 2 * Nd + t, Nd + t, 1.0); putA(a, U + 2 * Nd + t, 2 * Nd + t, 1.0);
+                putA(a, U + 2 * Nd + t, 4 * Nd + t, 1.0); putA(a, U + 2 * Nd + t, 5 * Nd + t, 1.0);
+            } else {
+                putA(a, t, Nd + t, 1.0); putA(a, Nd + t, 2 * Nd + t, 1.0); putA(a, 2 * Nd + t, t, 1.0);
+                putA(a, U + t, 4 * Nd + t, 1.0); putA(a, U + Nd + t, 5 * Nd + t, 1.0); putA(a, U + 3 * Nd + t, 3 * Nd + t, 1.0);
+                if (t < a.Ndata) putA(a, D + t, 3 * Nd + t, 1.0 / a.p0);
+            }
+        }
     } else if (a.system == GPK_GN_BURGERS) {                // src/PDEs.py:280-287 (F), :297-305 (A)
         const double alpha = a.p0, nu = a.p1;
         if (t < Nd) {
@@ -287,6 +310,34 @@ int exact_loss_chain(gpk_handle h, const Dims& d, bool after_main, bool* on_side
     return 0;
 }
 
+// The column layout gpk_gn_step runs a system in (BuildArgs::rev): 1 elliptic systems, 2 Eikonal, 3 Burgers, 4 Darcy on the GEMM-only
+// solve path, 0 = dense schedule.
+int step_layout(gpk_handle h, const gpk_gn_problem* p) {
+    const bool darcy_lz = p->system == GPK_GN_DARCY && h->tune.eikonal_lz && h->tune.use_dinv && p->Dinv && p->Dinv2 && p->dinv_block > 0;
+    return (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1
+         : (p->system == GPK_GN_EIKONAL && h->tune.eikonal_lz) ? 2 : (p->system == GPK_GN_BURGERS && h->tune.eikonal_lz) ? 3 : darcy_lz ? 4 : 0;
+}
+
+// The handle state that goes with it for the duration of one call: the Eikonal profile (GEMM-only solve path: the exact two-segment
+// profile for the solve and the products; the substitution path keeps the conservative closed form, which gpk_i_trsm_left_lz understands),
+// the staircase slope of the Burgers system; everything reset on the way out, whichever way that is.
+struct LayoutScope {
+    gpk_handle h;
+    LayoutScope(gpk_handle hh, const gpk_gn_problem* p, int rev) : h(hh) {
+        if (rev == 2 && h->tune.use_dinv && p->Dinv && p->dinv_block > 0 && h->tune.eikonal_lz != 2) h->stair = eikonal_profile(p->Nd);
+        h->lead_div = rev == 3 ? 3 : 1;
+    }
+    ~LayoutScope() { h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0; h->lead_div = 1; }
+    LayoutScope(const LayoutScope&) = delete;
+};
+
+// every factored row group comes with its inverted diagonal blocks (the GEMM-only solve path is available)
+bool all_dinv(gpk_handle h, const gpk_gn_problem* p, const Dims& d) {
+    if (!h->tune.use_dinv || p->dinv_block <= 0) return false;
+    for (int k = 0; k < d.ngroups; ++k) if (d.g[k].L && !d.g[k].Dinv) return false;
+    return true;
+}
+
 #define GPK_PROF_MARK(h, i) do { if ((h)->prof) { (h)->prof_phase = (i); GPK_HIP((h), hipEventRecord((h)->pev[i], (h)->stream)); } } while (0)
 
 // S <- [L^{-1}A | L^{-1}F], Hb <- alpha * S^T S (lower triangle, bordered).
@@ -334,8 +385,11 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
             const int Nd = p->Nd;
             if (k == 0) {
                 // a-part: only the columns [N_d, 4 N_d) are non-zero, a slope-1 staircase of their own (closed form on the sub-range),
-                // and the dense F column as a one-column solve; the v columns of these rows stay zero in W
-                GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, db, g.n, g.ldl, Sg + Nd, lds, Wg + Nd, lds, 3 * Nd, 3 * Nd, 0));
+                // and the dense F column as a one-column solve; the v columns of these rows stay zero in W.
+                // The 3 N_d columns do not depend on z (a permutation matrix against a fixed factor): with the result of
+                // gpk_gn_darcy_prepare at hand (p->Wa) that solve is not repeated -- the product below reads p->Wa / p->Ha instead
+                if (!(p->Wa && p->Ha))
+                    GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, db, g.n, g.ldl, Sg + Nd, lds, Wg + Nd, lds, 3 * Nd, 3 * Nd, 0));
                 GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, db, g.n, g.ldl, Sg + d.nz, lds, Wg + d.nz, lds, 1, 0, 0));
             } else {
                 h->stair = darcy_u_profile(Nd);                      // u-part: three segments (reset by the caller's guard)
@@ -419,6 +473,50 @@ __global__ __launch_bounds__(256) void structured_w_kernel(int nz, const double*
     if (threadIdx.x == 0) w[r] = v0[r] + ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// Structured solve of the other systems (round 6): d(z) per column, in the step's internal column order (column c holds the unknown at
+// staircase position nz-1-c).  The z-dependent entry of unknown j's column (see gn_build_kernel, family 1):
+//   Burgers  (src/PDEs.py:297-299):            v0_t: -alpha v2_t    v2_t: -alpha v0_t    v3_t: nu
+//   Eikonal  (src/PDEs.py:443-445):            v0_t: 0              v1_t: 2 v1_t / eps   v2_t: 2 v2_t / eps
+//   Darcy    (src/InverseProblems.py:131-135): w0_t: f_t exp(-w0_t) w1_t: -v1_t  w2_t: -v2_t  v0_t: 0  v1_t: -w1_t  v2_t: -w2_t
+__global__ void structured_coeff_general_kernel(int system, int Nd, int nz, int rev, double p0, double p1, const double* __restrict__ f,
+                                                const double* __restrict__ z, double* __restrict__ dcol) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nz) return;
+    const int blk = j / Nd, t = j - blk * Nd;
+    double v = 0.0;
+    if (system == GPK_GN_BURGERS) v = blk == 0 ? -p0 * z[Nd + t] : blk == 1 ? -p0 * z[t] : p1;
+    else if (system == GPK_GN_EIKONAL) v = blk == 0 ? 0.0 : 2.0 * z[j] / p0;
+    else if (system == GPK_GN_DARCY)
+        v = blk == 0 ? f[t] * exp(-z[t]) : blk == 1 ? -z[4 * Nd + t] : blk == 2 ? -z[5 * Nd + t] : blk == 3 ? 0.0 : blk == 4 ? -z[Nd + t] : -z[2 * Nd + t];
+    dcol[nz - 1 - stair_pos(rev, Nd, j)] = v;
+}
+
+// one workgroup per row r: W[r][c] = d[c] W1[r][c] + W2[r][c] for c < nz (16-byte pairs: ldw, lds even; nz may be odd).  The F column is
+// not touched (solved separately, one column, by the caller).  Above the staircase W1 and W2 hold zeros and zeros are written.
+__global__ __launch_bounds__(256) void structured_form_general_kernel(int nz, const double* __restrict__ W1, const double* __restrict__ W2, long ldw,
+                                                                      const double* __restrict__ dcol, double* __restrict__ W, long lds) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const long r = blockIdx.x;
+    const double* w1 = W1 + r * ldw;
+    const double* w2 = W2 + r * ldw;
+    double* w = W + r * lds;
+    for (int c = 2 * (int)threadIdx.x; c < nz; c += 512) {
+        if (c + 1 < nz) {
+            const d2 a = *reinterpret_cast<const d2*>(w1 + c), b = *reinterpret_cast<const d2*>(w2 + c);
+            const d2 d = *reinterpret_cast<const d2*>(dcol + c);
+            *reinterpret_cast<d2*>(w + c) = (d2){fma(d.x, a.x, b.x), fma(d.y, a.y, b.y)};
+        } else w[c] = fma(dcol[c], w1[c], w2[c]);
+    }
+}
+
+// C[i][j] += A[i][j] for j <= i (one workgroup per row): the cached a-part contribution of the Darcy step (gpk_gn_darcy_prepare)
+__global__ __launch_bounds__(256) void add_lower_kernel(int n, const double* __restrict__ A, long lda, double* __restrict__ Cm, long ldc) {
+    const long i = blockIdx.x;
+    const double* a = A + i * lda;
+    double* c = Cm + i * ldc;
+    for (int j = threadIdx.x; j <= (int)i; j += 256) c[j] += a[j];
+}
+
 __global__ void sub_kernel(long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = a[i] - b[i];
@@ -493,22 +591,34 @@ __global__ __launch_bounds__(1024) void gram_loss_kernel(int nz, const double* _
 
 
 extern "C" int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* p, double* S, int lds, double* W1, double* W2, double* v0, int ldw) {
-    if (!h || !S || !W1 || !W2 || !v0) return GPK_ERR_ARG;
+    if (!h || !S || !W1 || !W2) return GPK_ERR_ARG;
     Dims d;
     GPK_TRY(check_prob(h, p, d));
-    if (p->system != GPK_GN_ELLIPTIC) return gpk_bad_arg(h, "structured solve: elliptic system only");
+    const bool elliptic = p->system == GPK_GN_ELLIPTIC;
+    if (p->system == GPK_GN_ELLIPTIC_RELAXED) return gpk_bad_arg(h, "structured solve: not for the relaxed system");
+    if (elliptic && !v0) return GPK_ERR_ARG;
     const int nc = d.nz + 1;
     if (lds < nc || ldw < nc) return gpk_bad_arg(h, "structured solve: lds/ldw < nz+1");
+    // the other systems (round 6) are prepared -- and later stepped -- in the leading-zero layout of their GEMM-only solve path
+    const int rev = elliptic ? 1 : step_layout(h, p);
+    if (!elliptic && (rev < 2 || !all_dinv(h, p, d)))
+        return gpk_bad_arg(h, "structured solve: this system needs the inverted diagonal blocks of every factor (Dinv, dinv_block) and the leading-zero layout");
+    if (!elliptic && (ldw & 1)) return gpk_bad_arg(h, "structured solve: ldw must be even");
+    LayoutScope scope(h, p, elliptic ? 1 : rev);
+    gpk_gn_problem q = *p;                                           // (the Darcy a-part is solved here like everything else: no cache)
+    q.Wa = nullptr; q.Ha = nullptr;
     double* zero = nullptr;
     GPK_HIP(h, hipMalloc((void**)&zero, (size_t)d.nz * sizeof(double)));
     hipError_t e = hipMemsetAsync(zero, 0, (size_t)d.nz * sizeof(double), h->stream);
     int rc = e == hipSuccess ? 0 : gpk_fail(h, e, "hipMemsetAsync", __FILE__, __LINE__);
-    for (int fam = 1; fam <= 2 && rc == 0; ++fam) {                  // [I; 0; 0] -> W1;  [0; I; 0] with F(0) -> W2, v0
+    // elliptic: [I; 0; 0] -> W1;  [0; I; 0] with F(0) -> W2, v0.  Others: the 0/1 pattern of the z-dependent entries -> W1, the constant
+    // entries -> W2 (gn_build_kernel, family 1 / 2), all row groups, no F column
+    for (int fam = 1; fam <= 2 && rc == 0; ++fam) {
         double* W = nullptr;
-        rc = assemble_normal_equations(h, p, d, zero, S, lds, nullptr, nc, 1.0, 1, &W, fam);   // (no product: Wout is set)
+        rc = assemble_normal_equations(h, &q, d, zero, S, lds, nullptr, nc, 1.0, rev, &W, fam);   // (no product: Wout is set)
         if (rc) break;
         e = hipMemcpy2DAsync(fam == 1 ? W1 : W2, (size_t)ldw * 8, W, (size_t)lds * 8, (size_t)nc * 8, d.rows, hipMemcpyDeviceToDevice, h->stream);
-        if (e == hipSuccess && fam == 2)
+        if (e == hipSuccess && fam == 2 && elliptic)
             e = hipMemcpy2DAsync(v0, 8, W + d.nz, (size_t)lds * 8, 8, d.rows, hipMemcpyDeviceToDevice, h->stream);
         if (e != hipSuccess) rc = gpk_fail(h, e, "hipMemcpy2DAsync", __FILE__, __LINE__);
     }
@@ -533,6 +643,33 @@ extern "C" int gpk_gn_gram_prepare(gpk_handle h, const gpk_gn_problem* p, double
     GPK_TRY(gpk_i_dot(h, p->v0, p->v0, d.rows, pvec + 2L * nz));
     GPK_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+extern "C" int gpk_gn_darcy_prepare(gpk_handle h, const gpk_gn_problem* p, double* S, int lds, double* Wa, int ldwa, double* Ha, int ldha) {
+    if (!h || !S || !Wa || !Ha) return GPK_ERR_ARG;
+    Dims d;
+    GPK_TRY(check_prob(h, p, d));
+    if (p->system != GPK_GN_DARCY) return gpk_bad_arg(h, "darcy_prepare: Darcy system only");
+    if (!p->Dinv || !p->Dinv2 || p->dinv_block <= 0) return gpk_bad_arg(h, "darcy_prepare: needs Dinv, Dinv2 and dinv_block (the GEMM-only solve path)");
+    const int Nd = p->Nd, na = 3 * Nd, nc = d.nz + 1, db = p->dinv_block;
+    if (lds < nc || ldwa < na || ldha < na) return gpk_bad_arg(h, "darcy_prepare: lds/ldwa/ldha");
+    if (db != 256 && db != 512 && db != 1024 && db != 2048) return gpk_bad_arg(h, "gn: dinv_block must be 256, 512, 1024 or 2048");
+    const Group& ga = d.g[0];
+    double* zero = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&zero, (size_t)d.nz * sizeof(double)));
+    int rc = 0;
+    hipError_t e = hipMemsetAsync(zero, 0, (size_t)d.nz * sizeof(double), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(Wa, 0, (size_t)na * ldwa * sizeof(double), h->stream);   // (never written left of the staircase)
+    if (e != hipSuccess) rc = gpk_fail(h, e, "hipMemsetAsync", __FILE__, __LINE__);
+    // exactly the step's launches for this block (assemble_normal_equations, rev = 4, k = 0; the product of gpk_gn_step): same
+    // kernels, same shapes, same tile configurations -- only the destinations differ, hence bit-identical results
+    if (rc == 0) rc = build(h, p, zero, S, lds, d.nz, 1, 4, 0);
+    if (rc == 0) rc = gpk_i_trsm_left_dinv(h, ga.L, ga.Dinv, db, ga.n, ga.ldl, S + (long)ga.off * lds + Nd, lds, Wa, ldwa, na, na, 0);
+    if (rc == 0) rc = gpk_i_gemm(h, true, false, na, na, ga.n, 1.0, Wa, ldwa, Wa, ldwa, 0.0, Ha, ldha, true, na);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(zero);
+    return rc;
 }
 
 extern "C" int gpk_gn_dims(const gpk_gn_problem* p, int* nz, int* s_rows) {
@@ -576,16 +713,10 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     // t -- interleaved they form a staircase of slope 1/3 (rev = 3).  Darcy (two factors with different column supports) runs the
     // dense schedule.
     // Darcy (round 4): leading-zero layout with a piecewise profile per factor (darcy_u_profile), only on the GEMM-only solve path
-    const bool darcy_lz = p->system == GPK_GN_DARCY && h->tune.eikonal_lz && h->tune.use_dinv && p->Dinv && p->Dinv2 && p->dinv_block > 0;
-    const int rev = (p->system == GPK_GN_ELLIPTIC || p->system == GPK_GN_ELLIPTIC_RELAXED) ? 1
-                  : (p->system == GPK_GN_EIKONAL && h->tune.eikonal_lz) ? 2 : (p->system == GPK_GN_BURGERS && h->tune.eikonal_lz) ? 3 : darcy_lz ? 4 : 0;
-    struct StairGuard { gpk_handle h; ~StairGuard() { h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0; } } stair_guard{h};
-    // Eikonal on the GEMM-only solve path: the exact two-segment profile for the solve and for the products (pipelined or not); the
-    // substitution path (gpk_tune(10, 0)) keeps the conservative closed form, which gpk_i_trsm_left_lz understands
-    if (rev == 2 && h->tune.use_dinv && p->Dinv && p->dinv_block > 0 && h->tune.eikonal_lz != 2) h->stair = eikonal_profile(p->Nd);
-    struct SlopeGuard {                                              // the staircase slope is a property of this step's right-hand sides
-        gpk_handle h; explicit SlopeGuard(gpk_handle hh, int s) : h(hh) { h->lead_div = s; } ~SlopeGuard() { h->lead_div = 1; }
-    } slope_guard(h, rev == 3 ? 3 : 1);
+    if (p->system == GPK_GN_DARCY && p->Wa && p->Ha && (p->ldwa < 3 * p->Nd || p->ldha < 3 * p->Nd))
+        return gpk_bad_arg(h, "gn: ldwa/ldha < 3 Nd (gpk_gn_darcy_prepare)");
+    const int rev = step_layout(h, p);
+    LayoutScope layout_scope(h, p, rev);
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     const bool gram = h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
     double* d_loss = h->d_scalars;
@@ -622,6 +753,33 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         GPK_LAUNCH_CHECK(h);
         if (h->tune.exact_loss) { exact = true; GPK_TRY(exact_loss(h, p, d, z)); }   // reported loss: true substitution (round 6), as in the plain branch
         GPK_PROF_MARK(h, 1);
+    } else if (h->tune.structured && rev >= 2 && p->W1 && p->W2 && p->ldw >= nz + 1 && all_dinv(h, p, d)) {
+        // structured solve of the Burgers / Eikonal / Darcy systems (round 6, gpk_gn_structured_prepare): W = W1 diag(d(z)) + W2 in one
+        // memory-bound pass over all rows; the F column by its own one-column solve per factor (exact; rows without a factor copied)
+        if (h->tune.exact_loss) {
+            exact = true;
+            exact_late = h->tune.exact_loss == 1 && h->pipe_g && !h->pipe_unavailable;
+            if (exact_late) GPK_TRY(exact_loss_build(h, p, d, z));
+            else GPK_TRY(exact_loss(h, p, d, z));
+        }
+        GPK_PROF_MARK(h, 0);
+        const int nc = nz + 1, db = p->dinv_block;
+        GPK_TRY(gpk_i_workspace(h, (size_t)d.rows * lds * sizeof(double), &W));
+        h->work_sig[0] = -1;                                         // (the workspace no longer holds a solve of a known shape)
+        double* coef = S;                                            // nz doubles of scratch: row 0 of S left of its F column
+        structured_coeff_general_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(p->system, p->Nd, nz, rev, p->p0, p->p1, p->rhs_f, z, coef);
+        structured_form_general_kernel<<<d.rows, 256, 0, h->stream>>>(nz, p->W1, p->W2, p->ldw, coef, W, lds);
+        GPK_LAUNCH_CHECK(h);
+        GPK_TRY(build(h, p, z, S, lds, nz, 0));                      // F(z) into column nz of S (every row has an entry)
+        for (int k = 0; k < d.ngroups; ++k) {
+            const Group& g = d.g[k];
+            if (g.n <= 0) continue;
+            if (g.L) GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, db, g.n, g.ldl, S + (long)g.off * lds + nz, lds, W + (long)g.off * lds + nz, lds, 1, 0, 0));
+            else GPK_HIP(h, hipMemcpy2DAsync(W + (long)g.off * lds + nz, (size_t)lds * 8, S + (long)g.off * lds + nz, (size_t)lds * 8, 8, g.n,
+                                             hipMemcpyDeviceToDevice, h->stream));
+        }
+        (void)nc;
+        GPK_PROF_MARK(h, 1);
     } else {
         // the loss of the iterate this step starts from, exact (true substitution with the factors, one vector), in front of the solve
         if (h->tune.exact_loss) {
@@ -652,8 +810,15 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         h->stair = darcy_u_profile(Nd); h->stair_col0 = 0; h->stair_row0 = 0;
         int rc = gpk_i_gemm(h, true, false, nc, nc, d.rows - gu.off, 1.0, Wu, lds, Wu, lds, 0.0, Hb, ldh, true, 1);
         h->stair = GpkStair();
-        if (rc == 0) rc = gpk_i_gemm(h, true, false, 3 * Nd, 3 * Nd, ga.n, 1.0, Wa + Nd, lds, Wa + Nd, lds, 1.0, Hb + (long)Nd * ldh + Nd, ldh, true, 3 * Nd);
-        if (rc == 0) rc = gpk_i_gemm(h, true, false, 1, 3 * Nd, ga.n, 1.0, Wa + nz, lds, Wa + Nd, lds, 1.0, Hb + (long)nz * ldh + Nd, ldh, false, 3 * Nd);
+        const bool cached_a = p->Wa && p->Ha;                       // (checked: ldwa, ldha >= 3 N_d)
+        if (rc == 0 && cached_a) {
+            add_lower_kernel<<<3 * Nd, 256, 0, h->stream>>>(3 * Nd, p->Ha, p->ldha, Hb + (long)Nd * ldh + Nd, ldh);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = gpk_fail(h, e, "add_lower_kernel", __FILE__, __LINE__);
+        } else if (rc == 0)
+            rc = gpk_i_gemm(h, true, false, 3 * Nd, 3 * Nd, ga.n, 1.0, Wa + Nd, lds, Wa + Nd, lds, 1.0, Hb + (long)Nd * ldh + Nd, ldh, true, 3 * Nd);
+        if (rc == 0) rc = gpk_i_gemm(h, true, false, 1, 3 * Nd, ga.n, 1.0, Wa + nz, lds, cached_a ? p->Wa : Wa + Nd, cached_a ? p->ldwa : lds, 1.0,
+                                     Hb + (long)nz * ldh + Nd, ldh, false, 3 * Nd);
         if (rc == 0) rc = gpk_i_gemm(h, true, false, 1, 1, ga.n, 1.0, Wa + nz, lds, Wa + nz, lds, 1.0, Hb + (long)nz * ldh + nz, ldh, false);
         h->prof_phase = ph;
         GPK_TRY(rc);

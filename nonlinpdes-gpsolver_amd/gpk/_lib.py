@@ -19,7 +19,8 @@ class GNProblemStruct(C.Structure):
                 ('L', C.c_void_p), ('ldl', C.c_int), ('L2', C.c_void_p), ('ldl2', C.c_int),
                 ('Dinv', C.c_void_p), ('Dinv2', C.c_void_p), ('dinv_block', C.c_int),
                 ('W1', C.c_void_p), ('W2', C.c_void_p), ('v0', C.c_void_p), ('ldw', C.c_int),
-                ('G', C.c_void_p), ('ldg', C.c_int), ('pvec', C.c_void_p)]
+                ('G', C.c_void_p), ('ldg', C.c_int), ('pvec', C.c_void_p),
+                ('Wa', C.c_void_p), ('ldwa', C.c_int), ('Ha', C.c_void_p), ('ldha', C.c_int)]
 
 
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
@@ -93,6 +94,7 @@ PROTOTYPES = {
     'gpk_gn_step': (_i, [_vp, _pp, _vp, _d, _vp, _i, _vp, _i, _vp, _pd, _pi]),
     'gpk_gn_structured_prepare': (_i, [_vp, _pp, _vp, _i, _vp, _vp, _vp, _i]),
     'gpk_gn_gram_prepare': (_i, [_vp, _pp, _vp, _i, _vp]),
+    'gpk_gn_darcy_prepare': (_i, [_vp, _pp, _vp, _i, _vp, _i, _vp, _i]),
     'gpk_gn_build': (_i, [_vp, _pp, _vp, _vp, _i]),
     'gpk_gn_build_rev': (_i, [_vp, _pp, _vp, _vp, _i]),
     'gpk_axpy': (_i, [_vp, _i, _d, _vp, _vp]),

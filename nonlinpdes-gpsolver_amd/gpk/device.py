@@ -1,6 +1,7 @@
 """Thin object layer over the C ABI: a context (handle + stream), device arrays with a padded leading dimension,
 and the calls of include/gpk.h with numpy-friendly signatures."""
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -104,8 +105,11 @@ class DeviceArray:
 class GNProblem:
     """Device-side description of one equation's Gauss-Newton system (gpk_gn_problem)."""
 
-    def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True, structured=False):
+    def __init__(self, ctx, system, Nd, Nb, rhs_f, bdy_g, L, p0=0.0, p1=0.0, pen_lambda=0.0, data_u=None, L2=None, dinv=True, structured=False,
+                 cache_a=None):
         """structured: False (default: the reference's operation sequence every step), True / 1 (prepare_structured), 2 (+ prepare_gram).
+        cache_a (Darcy only): keep the iteration-independent a-part of the step (prepare_darcy: bit-identical iterates, less work per step);
+        None = on unless GPK_DARCY_CACHE=0.
         dinv: also compute the inverses of the diagonal blocks of the factor(s) once (gpk_trtri_diag; True = blocks of
         dinv_block_for(order) rows, or 256 / 512 / 1024 / 2048), so that the solve S = L^{-1}[A | F] of every step runs as GEMMs only."""
         self.ctx = ctx
@@ -139,15 +143,27 @@ class GNProblem:
         self.nz, self.rows = nz.value, rows.value
         self._S = self._H = self._delta = self._work = None
         self.W1 = self.W2 = self.v0 = self.G = self.pvec = None
+        self.Wa = self.Ha = None
+        self.darcy_prepare_ms = self.structured_prepare_ms = None
+        if cache_a is None:
+            cache_a = os.environ.get('GPK_DARCY_CACHE', '1') != '0'
+        if cache_a and s.system == SYSTEM['Darcy_flow2d'] and dinv:
+            self.prepare_darcy()
         if structured:
             self.prepare_structured()
             if int(structured) == 2:
                 self.prepare_gram()
 
     def prepare_structured(self):
-        """OPTIONAL (elliptic system): precompute W1 = L^{-1}[I;0;0], W2 = L^{-1}[0;I;0], v0 = L^{-1}F(0) once
-        (gpk_gn_structured_prepare); every later gn_step then forms [L^{-1}A(z) | L^{-1}F(z)] = [W1 diag(d) + W2 | v0 + W1 a + W2 z]
-        in one memory-bound pass instead of the triangular solve.  Not the reference's per-step operation sequence: opt-in."""
+        """OPTIONAL: precompute the z-independent solves once (gpk_gn_structured_prepare).  Elliptic system: W1 = L^{-1}[I;0;0],
+        W2 = L^{-1}[0;I;0], v0 = L^{-1}F(0); every later gn_step forms [L^{-1}A(z) | L^{-1}F(z)] = [W1 diag(d) + W2 | v0 + W1 a + W2 z]
+        in one memory-bound pass instead of the triangular solve.  Burgers / Eikonal / Darcy (round 6): A(z) = A1 diag(d(z)) + A2 with
+        constant 0/1 patterns, W1 = L^{-1}A1, W2 = L^{-1}A2; the step forms L^{-1}A(z) = W1 diag(d(z)) + W2 and solves only the F column.
+        Not the reference's per-step operation sequence: opt-in."""
+        import time
+        if self.struct.system == SYSTEM['Nonlinear_elliptic_relaxed']:
+            raise GpkError('structured solve: not available for the relaxed system')
+        self.ctx.synchronize(); t0 = time.perf_counter()
         S, _, _, _ = self.workspace()
         ld = S.ld
         self.W1 = DeviceArray(self.ctx, self.rows, self.nz + 1, ld)
@@ -156,6 +172,22 @@ class GNProblem:
         self.ctx._chk(self.ctx.lib.gpk_gn_structured_prepare(self.ctx.h, C.byref(self.struct), S.ptr, S.ld, self.W1.ptr, self.W2.ptr,
                                                              self.v0.ptr, ld))
         self.struct.W1, self.struct.W2, self.struct.v0, self.struct.ldw = self.W1.ptr, self.W2.ptr, self.v0.ptr, ld
+        self.ctx.synchronize(); self.structured_prepare_ms = 1e3 * (time.perf_counter() - t0)
+
+    def prepare_darcy(self):
+        """Darcy: the a-part rows of GN_loss ([w1; w2; w0] against L_a, reference src/InverseProblems.py:137-146) do not involve z_old, so
+        W_a = L_a^{-1} A_a and W_a^T W_a are the same in every step: computed once here with the step's own launches (gpk_gn_darcy_prepare),
+        after which every gn_step skips that solve and that product.  Bit-identical iterates; 2 x (3 N_d)^2 doubles."""
+        import time
+        S, _, _, _ = self.workspace()
+        na = 3 * self.struct.Nd
+        ld = pad_ld(na)
+        self.Wa = DeviceArray(self.ctx, na, na, ld)
+        self.Ha = DeviceArray(self.ctx, na, na, ld)
+        self.ctx.synchronize(); t0 = time.perf_counter()
+        self.ctx._chk(self.ctx.lib.gpk_gn_darcy_prepare(self.ctx.h, C.byref(self.struct), S.ptr, S.ld, self.Wa.ptr, ld, self.Ha.ptr, ld))
+        self.ctx.synchronize(); self.darcy_prepare_ms = 1e3 * (time.perf_counter() - t0)
+        self.struct.Wa, self.struct.ldwa, self.struct.Ha, self.struct.ldha = self.Wa.ptr, ld, self.Ha.ptr, ld
 
     def prepare_gram(self):
         """OPTIONAL second level (needs prepare_structured): the Gram blocks G = [W1 W2]^T [W1 W2] and W^T v0 once

@@ -1,6 +1,8 @@
 """Darcy_flow2d inverse problem with the reference's public API (src/InverseProblems.py:16-196): two coupled GPs
 (log-permeability a, pressure u), two Gram matrices / Cholesky factors, 6*N_domain unknowns, noisy observations of u
 at the first N_data collocation points."""
+import os
+
 import numpy as onp
 from numpy import random
 
@@ -92,7 +94,8 @@ class Darcy_flow2d(_GPEquation):
             if getattr(self, '_dL_u', None) is None:
                 raise RuntimeError('call Gram_matrix() and Gram_Cholesky() first')
             self._prob = gpk.GNProblem(get_context(), 'Darcy_flow2d', self.N_domain, self.N_boundary, self.rhs_f, self.bdy_g,
-                                       self._dL_u, p0=float(self.noise_level), data_u=self.data_u, L2=self._dL_a)
+                                       self._dL_u, p0=float(self.noise_level), data_u=self.data_u, L2=self._dL_a,
+                                       structured=min(int(os.environ.get('GPK_STRUCTURED', '0') or 0), 1))   # (opt-in, round 6: gpk_gn_structured_prepare)
         return self._prob
 
     # loss / grad_loss inherited (device); GN_loss restated on the host for API parity (reference :126-147)

@@ -78,7 +78,10 @@ class _GPEquation(object):
             p0, p1, lam = self._gn_params()
             # GPK_STRUCTURED=1 / 2 (opt-in, elliptic system only; 2 adds the Gram level, gpk_gn_gram_prepare): the z-independent solves are done once and every step forms
             # [L^{-1}A(z) | L^{-1}F(z)] from them (gpk_gn_structured_prepare) -- same iterates, about half the time per step
-            structured = (int(os.environ.get('GPK_STRUCTURED', '0') or 0) if self._system == 'Nonlinear_elliptic' else 0)
+            # (round 6: GPK_STRUCTURED=1 also for the Burgers and Eikonal systems, and the Darcy system in InverseProblems.py: A(z) = A1 diag(d(z)) + A2)
+            structured = int(os.environ.get('GPK_STRUCTURED', '0') or 0)
+            if self._system != 'Nonlinear_elliptic':
+                structured = min(structured, 1)                   # (the Gram level exists for the elliptic system only)
             self._prob = gpk.GNProblem(get_context(), self._system, self.N_domain, self.N_boundary, self.rhs_f, self.bdy_g,
                                        self._dL, p0=p0, p1=p1, pen_lambda=lam, structured=structured)
         return self._prob

@@ -305,3 +305,53 @@ def test_fused_panel_schedule_in_the_pipelined_gn_step():
         ctx.lib.gpk_debug_set(48, 1)
         ctx.close()
     assert np.linalg.norm(sols[0] - sols[1]) <= 1e-9 * np.linalg.norm(sols[1])
+
+
+@pytest.mark.parametrize('Nd,Nb,Ndata', [(333, 50, 20), (640, 128, 40), (1100, 150, 60)])
+def test_darcy_cached_a_part_is_bit_identical_to_the_per_step_path(Nd, Nb, Ndata):
+    """Round 6: the a-part rows of the Darcy system ([w1; w2; w0] against L_a, reference src/InverseProblems.py:137-146) do not involve
+    z_old -- W_a = L_a^{-1} A_a and W_a^T W_a are the same in every step.  gpk_gn_darcy_prepare computes them once with the step's own
+    launches (default of GNProblem; cache_a=False / GPK_DARCY_CACHE=0 recompute them every step): iterates, losses, the step vector and
+    the pivot status must agree BIT FOR BIT, at sizes where no boundary of the profile is tile-aligned, where all are, and with several
+    inverted blocks per factor; the cached path against the oracle as well."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(7 + Nd)
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = np.ones(Nd); g = np.zeros(Nb)
+    data = 0.05 * np.sin(np.pi * Xd[:Ndata, 0]) * np.sin(np.pi * Xd[:Ndata, 1]) + 1e-3 * rng.normal(size=Ndata)
+    Tu, _ = ctx.assemble('Darcy_u', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+    Ta, _ = ctx.assemble('Darcy_a', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+    assert ctx.potrf(Tu) == 0 and ctx.potrf(Ta) == 0
+    Lu, La = np.tril(Tu.download()), np.tril(Ta.download())
+    z0 = 0.3 * rng.normal(size=6 * Nd)
+    out = {}
+    for cached in (True, False):
+        prob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, f, g, Tu, p0=1e-3, data_u=data, L2=Ta, cache_a=cached)
+        assert (prob.Wa is not None) == cached and bool(prob.struct.Ha) == cached
+        z = ctx.array(z0)
+        hist, deltas = [], []
+        for _ in range(3):
+            loss, info = ctx.gn_step(prob, z)
+            assert info == 0
+            hist.append(loss)
+            deltas.append(prob.workspace()[2].download().copy())
+        hist.append(ctx.gn_loss(prob, z))
+        out[cached] = (z.download().copy(), hist, deltas)
+        prob.release_workspace()
+    assert np.array_equal(out[True][0], out[False][0]) and out[True][1] == out[False][1]
+    for a, b in zip(out[True][2], out[False][2]):
+        assert np.array_equal(a, b)
+    sol_ref, hist_ref = O.gn_method(O.DarcySystem(f, g, data, 1e-3), [La, Lu], z0, 3, 1)
+    assert np.linalg.norm(out[True][0] - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
+    np.testing.assert_allclose(out[True][1], hist_ref, rtol=1e-6)
+    # bad arguments of the prepare call: wrong system, missing inverted blocks, leading dimensions too small
+    prob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, f, g, Tu, p0=1e-3, data_u=data, L2=Ta, cache_a=False)
+    S = prob.workspace()[0]
+    import ctypes as C
+    W = gpk.DeviceArray(ctx, 3 * Nd, 3 * Nd, gpk.device.pad_ld(3 * Nd))
+    assert ctx.lib.gpk_gn_darcy_prepare(ctx.h, C.byref(prob.struct), S.ptr, S.ld, W.ptr, 3 * Nd - 1, W.ptr, W.ld) < 0
+    st = gpk.device.GNProblemStruct.from_buffer_copy(prob.struct)
+    st.Dinv2 = None
+    assert ctx.lib.gpk_gn_darcy_prepare(ctx.h, C.byref(st), S.ptr, S.ld, W.ptr, W.ld, W.ptr, W.ld) < 0
+    ctx.close()
