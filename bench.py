@@ -1088,11 +1088,14 @@ def run_sharded(args, workload, steps=None, warmup=None, solo=False):
         if mgpu and probe_allowed('exchange_of_S'):
             # and for the exchange of the column shards of S: one all-gather, or one broadcast per shard on the communication stream with
             # the block-row products of Hb issued behind the arrivals (native executor only)
-            xt = ab((('all_gather', 0), ('broadcasts_chased_by_products', 1)), lambda f: set_mode(overlap_s=f))
-            keep = int(xt['broadcasts_chased_by_products'] < xt['all_gather'])
-            set_mode(overlap_s=keep)
+            # (round 6: third form where the point-to-point entry points are bound -- the DIRECT exchange, one transfer per peer inside one
+            # ncclGroupStart / ncclGroupEnd: on xGMI every peer has a link of its own)
+            forms = (('all_gather', 0), ('broadcasts_chased_by_products', 1)) + ((('direct_p2p', 2),) if mgpu.has_p2p() else ())
+            xt = ab(forms, lambda f: set_mode(overlap_s=f))
+            keep = min(forms, key=lambda nf: xt[nf[0]])
+            set_mode(overlap_s=keep[1])
             mode_probe['step_ms_by_exchange_of_S'] = xt
-            mode_probe['overlap_s_kept'] = bool(keep)
+            mode_probe['overlap_s_kept'] = keep[0]
         mode_probe['probe_wall_s'] = t_probe[0]
     for _ in range(max(warmup - warmup_run, 0)):
         losses.append(step())

@@ -152,7 +152,7 @@ def compact_predicted(p):
         return {'error': short(p['error'], 120)}
     r1 = lambda v: round(v, 1) if isinstance(v, float) else v
     out = {'fabric_gbs': r1(((p.get('inputs') or {}).get('fabric') or {}).get('bcast_gbs')),
-           'keys': 'chol=[lookahead,sequential] xchg=[allgather_padded,bcasts_exact] hb=[replicated,sharded] ms'}
+           'keys': 'chol=[lookahead,sequential] xchg=[allgather_padded,bcasts_exact,direct_p2p] hb=[replicated,sharded] ms'}
     for k, v in p.items():
         if k == 'inputs' or not isinstance(v, dict):
             continue

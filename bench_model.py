@@ -15,7 +15,8 @@ Model (all times ms; K = ceil(N / nb) panels, panel k has m_k = N - k nb rows):
   sequential        sum_k t_pf + t_bc + t_up
   look-ahead        t_pf(0) + t_bc(0) + sum_k max(t_up(k), t_pf(k+1) + t_bc(k+1))
   step              solve / P + exchange(S) + product x imbalance / P + all-gather(Hb lower parts) + Cholesky(Hb) + tail
-  exchange(S)       all-gather: (P-1) x widest shard / B_allgather ; broadcasts: all shards, one after the other, / B_bcast
+  exchange(S)       all-gather: (P-1) x widest shard / B_allgather ; broadcasts: all shards, one after the other, / B_bcast ;
+                    direct (grouped send / recv, round 6): widest shard / B_link -- the P - 1 incoming shards use P - 1 links at once
                     (the broadcast form overlaps the block-row products with the arrivals: the model takes max(exchange, product) + the
                     last shard's share instead of the sum)
 R_panel, R_gemm are fitted so that P = 1 reproduces the measured 1-GPU factorisation.  Pure Python + the column-shard rule of
@@ -24,7 +25,8 @@ gpk_mg_column_bounds restated (tests/test_bench_flow.py checks the restatement a
 import math
 
 LINK_GBS = 153.0                      # one xGMI link, per direction (MI355X_MICROARCH.md)
-DEFAULT_FABRIC = {'bcast_gbs': 0.8 * LINK_GBS, 'allgather_gbs': 0.8 * LINK_GBS, 'latency_ms': 0.03, 'source': 'assumed: one xGMI link x 0.8'}
+DEFAULT_FABRIC = {'bcast_gbs': 0.8 * LINK_GBS, 'allgather_gbs': 0.8 * LINK_GBS, 'p2p_link_gbs': 0.8 * LINK_GBS, 'links': 7, 'latency_ms': 0.03,
+                  'source': 'assumed: one xGMI link x 0.8'}
 # round-5 driver run, config 5 on ONE MI355X (BENCH_r05 / bench_detail.json: sharded_config): replaced by the same job's own 1-GPU point
 DEFAULT_ONE_GPU = {'cholesky_theta_ms': 245.0, 'step_ms': 299.0, 'cholesky_hb_ms': 37.0, 'tail_ms': 3.0,
                    'solve_flops': 1.1212e13, 'product_flops': 6.009e12, 'source': 'round-5 driver run on one MI355X'}
@@ -113,20 +115,25 @@ def predict(N, nz, P, nb=512, one_gpu=None, fabric=None, col_align=128):
     prod = prod1 * max(share) / max(sum(share), 1.0)
     lat = f['latency_ms']
     if P == 1:
-        ex = {'all_gather_padded': 0.0, 'broadcasts_exact': 0.0}
-        hb_gather = 0.0
+        ex = {'all_gather_padded': 0.0, 'broadcasts_exact': 0.0, 'direct_p2p': 0.0}
+        hb_gather = hb_direct = 0.0
     else:
+        # direct exchange (grouped send / recv): a rank receives P - 1 shards over min(P - 1, links) links at once; the widest shard bounds it
+        rounds = -(-(P - 1) // max(int(f.get('links', 7)), 1))
         ex = {'all_gather_padded': (P - 1) * widest / (f['allgather_gbs'] * 1e6) + lat,
-              'broadcasts_exact': total_bytes / (f['bcast_gbs'] * 1e6) + P * lat}
+              'broadcasts_exact': total_bytes / (f['bcast_gbs'] * 1e6) + P * lat,
+              'direct_p2p': rounds * widest / (f['p2p_link_gbs'] * 1e6) + lat}
         hshare = max(sum(min(nb, nc - i * nb) * (i * nb + min(nb, nc - i * nb)) for i in range(r, nblk, P)) for r in range(P))
         hb_gather = (P - 1) * 8.0 * hshare / (f['allgather_gbs'] * 1e6) + lat
+        hb_direct = rounds * 8.0 * hshare / (f['p2p_link_gbs'] * 1e6) + lat
     rg_h, rp_h = _fit_rates(nc, nb, g['cholesky_hb_ms'])
     hb = {'replicated': g['cholesky_hb_ms'], 'panel_sharded': _potrf(nc, nb, P, f, rg_h, rp_h, True)}
     last = 8.0 * N * widths[-1] / (f['bcast_gbs'] * 1e6) if P > 1 else 0.0
     step_by_exchange = {'all_gather': solve + ex['all_gather_padded'] + prod,
-                        'broadcasts_chased_by_products': solve + max(ex['broadcasts_exact'], prod) + min(last, prod) if P > 1 else solve + prod}
-    rest = hb_gather + g['tail_ms']
-    step = {xk: {hk: xv + rest + hv for hk, hv in hb.items()} for xk, xv in step_by_exchange.items()}
+                        'broadcasts_chased_by_products': solve + max(ex['broadcasts_exact'], prod) + min(last, prod) if P > 1 else solve + prod,
+                        'direct_p2p': solve + ex['direct_p2p'] + prod}
+    step = {xk: {hk: xv + (hb_direct if xk == 'direct_p2p' else hb_gather) + g['tail_ms'] + hv for hk, hv in hb.items()}
+            for xk, xv in step_by_exchange.items()}
     best = min(v for d in step.values() for v in d.values())
     return {'ranks': P, 'shard_widths': widths, 'shard_max_over_mean': max(widths) * P / float(nc),
             'cholesky_theta_ms': chol, 'exchange_of_S_ms': ex, 'cholesky_of_Hb_ms': hb, 'all_gather_Hb_ms': hb_gather,
@@ -134,6 +141,7 @@ def predict(N, nz, P, nb=512, one_gpu=None, fabric=None, col_align=128):
             'predicted_vs_1gpu': g['step_ms'] / best,
             'prefer': {'lookahead': chol['lookahead'] <= chol['sequential'],
                        'overlap_s': min(step['broadcasts_chased_by_products'].values()) < min(step['all_gather'].values()),
+                       'exchange': min(step, key=lambda k: min(step[k].values())),
                        'shard_hb': hb['panel_sharded'] < hb['replicated']}}
 
 
@@ -149,6 +157,9 @@ def fabric_from_preflight(pre, nbytes=139 * 2 ** 20):
             out['bcast_gbs'] = min(vals)
     if pre.get('allgather_gbs_received'):                            # bytes received per rank / time: the unit the model divides by
         out['allgather_gbs'] = pre['allgather_gbs_received']
+    if pre.get('direct_gbs_received') and pre.get('ranks_seen_by_rccl', 0) > 1:
+        # the preflight's direct exchange received (P - 1) equal parts at once: per-link rate = total / (P - 1) when the links are independent
+        out['p2p_link_gbs'] = pre['direct_gbs_received'] / (pre['ranks_seen_by_rccl'] - 1)
     if out:
         out['source'] = 'preflight of the bound collectives'
     return out or None
@@ -159,7 +170,7 @@ def table(N=34000, nz=16000, nb=512, one_gpu=None, fabric=None, ranks=(2, 4, 8))
     g = dict(DEFAULT_ONE_GPU, **(one_gpu or {}))
     f = dict(DEFAULT_FABRIC, **(fabric or {}))
     out = {'inputs': {'one_gpu': {k: g[k] for k in ('cholesky_theta_ms', 'step_ms', 'cholesky_hb_ms', 'source')},
-                      'fabric': {k: f[k] for k in ('bcast_gbs', 'allgather_gbs', 'source')}}}
+                      'fabric': {k: f[k] for k in ('bcast_gbs', 'allgather_gbs', 'p2p_link_gbs', 'source')}}}
     for P in ranks:
         p = predict(N, nz, P, nb, g, f)
         out[str(P)] = {'cholesky_theta_ms': p['cholesky_theta_ms'], 'exchange_of_S_ms': p['exchange_of_S_ms'],

@@ -1,6 +1,7 @@
 /* gpk_dev.h -- entry points of libgpk_dev.so, the DEVELOPMENT build of the library (csrc/Makefile): the product sources compiled with
  * -DGPK_DEV plus csrc/dev/.  It exports everything libgpk.so exports (include/gpk.h, gpk_mg.h, gpk_debug.h) and, on top,
- *   - the superseded kernel designs of csrc/dev/gpk_factor_retired.inc behind their gpk_tune keys (5 = 0, 7 = 1, 21 = 0 / 2, 4 = 2),
+ *   - the look-ahead factorisation of round 5 (measured, not adopted: gpk_tune key 54) -- the superseded kernel designs of rounds 1-2
+ *     (gpk_tune keys 5 = 0, 7 = 1, 21 = 0 / 2, 4 = 2) were removed in round 6,
  *   - the shader-clock stamps of the diagonal-block kernels,
  *   - probes that documented hardware behaviour and the micro-benchmarks that fix the roofline denominators.
  * tests/ and tools/ load it explicitly (gpk.Context(dev=True)); bench.py, the drivers and the host API never do.

@@ -45,11 +45,20 @@ typedef struct gpk_mg_ctx* gpk_mg_handle;
 typedef int (*gpk_mg_bcast_fn)(const void* sendbuf, void* recvbuf, size_t count, int datatype, int root, void* comm, void* stream);
 typedef int (*gpk_mg_allgather_fn)(const void* sendbuf, void* recvbuf, size_t sendcount, int datatype, void* comm, void* stream);
 
+/* signatures of ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd: the DIRECT exchange of the step (round 6, key 3 = 2 below) */
+typedef int (*gpk_mg_send_fn)(const void* sendbuf, size_t count, int datatype, int peer, void* comm, void* stream);
+typedef int (*gpk_mg_recv_fn)(void* recvbuf, size_t count, int datatype, int peer, void* comm, void* stream);
+typedef int (*gpk_mg_group_fn)(void);
+
 /* h: this process' handle (its device, its stream = the stream results are ordered on).  panel_width: multiple of 64, <= 512. */
 int gpk_mg_create(gpk_handle h, int rank, int world, int panel_width, gpk_mg_handle* out);
 int gpk_mg_destroy(gpk_mg_handle mg);                          /* also destroys a communicator created by gpk_mg_rccl_init */
 /* an existing communicator + the two collectives of the RCCL build that created it (or stand-ins) */
 int gpk_mg_set_comm(gpk_mg_handle mg, void* comm, gpk_mg_bcast_fn bcast, gpk_mg_allgather_fn allgather);
+/* optional: the four point-to-point entry points of the same library (or stand-ins); gpk_mg_rccl_init binds ncclSend / ncclRecv /
+ * ncclGroupStart / ncclGroupEnd by itself when the library has them.  gpk_mg_has_p2p: 1 when they are bound. */
+int gpk_mg_set_p2p(gpk_mg_handle mg, gpk_mg_send_fn send, gpk_mg_recv_fn recv, gpk_mg_group_fn group_start, gpk_mg_group_fn group_end);
+int gpk_mg_has_p2p(gpk_mg_handle mg);
 /* librccl_path: NULL = "librccl.so.1" by the loader's search order.  host_id128: 128 bytes. */
 /* gpk_mg_rccl_probe: can this process load the library and find ncclGetUniqueId / ncclCommInitRank / ncclBroadcast /
  * ncclAllGather?  No communicator, no GPU call -- so that all ranks can agree on the answer BEFORE any of them enters
@@ -62,7 +71,10 @@ int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* hos
  * key 3: exchange of the column shards of S in the step (0 = one all-gather, every shard padded to the widest; 1 = one broadcast
  * per shard, exact sizes, on the communication stream, the block-row products of Hb issued behind the arrival of the shards they
  * read; -1 = default: the form that puts fewer bytes on a link -- broadcasts when (world - 1) x widest shard > all columns, which
- * holds from 4 ranks on for the work-balanced shards of BASELINE config 5 (widest / mean 1.57 at 4 ranks, 1.79 at 8)) */
+ * holds from 4 ranks on for the work-balanced shards of BASELINE config 5 (widest / mean 1.57 at 4 ranks, 1.79 at 8);
+ * 2 = DIRECT exchange: inside one ncclGroupStart / ncclGroupEnd every rank sends its shard to every peer and receives theirs (exact
+ * sizes).  xGMI is point-to-point -- one link per peer -- so the world - 1 transfers of a rank use world - 1 links at once where a
+ * ring collective is bound by one; the block rows of Hb are exchanged the same way.  Needs gpk_mg_has_p2p; bench.py times all forms) */
 int gpk_mg_set_option(gpk_mg_handle mg, int key, int value);
 
 /* Health check of the bound collectives (every rank calls it): a broadcast from rank 0 and an all-gather of small buffers,
@@ -74,6 +86,8 @@ int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok);
  * timed with HIP events.  host_bcast_ms[world]: average ms per broadcast and root; *host_allgather_ms: average ms per all-gather;
  * *host_ranks_seen: distinct ranks the all-gather delivered (== world when the communicator spans the job). */
 int gpk_mg_preflight(gpk_mg_handle mg, size_t bytes, int reps, double* host_bcast_ms, double* host_allgather_ms, int* host_ranks_seen);
+/* the same for the direct exchange: every rank sends bytes / world to every peer and receives as much from each; *host_ms per exchange */
+int gpk_mg_preflight_p2p(gpk_mg_handle mg, size_t bytes, int reps, double* host_ms);
 
 /* gpk_potrf over all ranks: A (n x n, ld lda) holds the SAME symmetric matrix on every rank on entry and the complete
  * lower factor on every rank on return.  host_info: LAPACK info, identical on all ranks (one host read at the end). */

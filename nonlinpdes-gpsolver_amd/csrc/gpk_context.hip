@@ -196,9 +196,12 @@ extern "C" int gpk_timer_stop(gpk_handle h, double* ms) {
 extern "C" int gpk_tune(gpk_handle h, int key, int value) {
     if (!h) return GPK_ERR_ARG;
     GpkTune& t = h->tune;
+    // values that selected a superseded design (potf2 + row solve as two launches, persistent outer-block kernel, first / third panel kernel,
+    // flag-chained single-vector solve): removed in round 6 -- they had lost every comparison since round 2 (git 4be18eb holds them)
+    if ((key == 5 && value == 0) || (key == 7 && value != 0) || (key == 21 && value != 1) || (key == 4 && value == 2))
+        return gpk_bad_arg(h, "gpk_tune: this variant was removed in round 6");
 #ifndef GPK_DEV
-    // values that select a superseded design: those kernels are not in this library (csrc/dev/, libgpk_dev.so)
-    if ((key == 5 && value == 0) || (key == 7 && value != 0) || (key == 21 && value != 1) || (key == 4 && value == 2) || key == 11 || (key == 54 && value != 0))
+    if (key == 11 || (key == 54 && value != 0))
         return gpk_bad_arg(h, "gpk_tune: this variant exists only in the development build (libgpk_dev.so)");
 #endif
     switch (key) {

@@ -15,8 +15,8 @@
 //                       (the inverses of its diagonal BLOCKS come from gpk_i_trtri_diag, by substitution; accuracy: see there)
 //   trsm_right_lt     = X1 <- X1 L11^{-T}; X2 -= X1 L21^T; X2 <- X2 L22^{-T}
 //   trsv              = single-vector solves in one launch, workgroups chained through data-tagged granules (trsv_gran_kernel)
-// Superseded designs (first / third panel kernel, persistent outer-block kernel, flag-chained trsv, potf2 + row-solve launches) live
-// in dev/gpk_factor_retired.inc and are compiled into libgpk_dev.so only (-DGPK_DEV).
+// Superseded designs (first / third panel kernel, persistent outer-block kernel, flag-chained trsv, potf2 + row-solve launches) were
+// removed in round 6 (they had lost every comparison since round 2; the last tree that holds them: git 4be18eb, csrc/dev/gpk_factor_retired.inc).
 // True substitution everywhere except trsm_left_dinv.  The recursions split at multiples of 64/128/256 so that sub-blocks stay
 // 16-byte aligned for the GEMM's vector loads.
 #include "gpk_common.h"
@@ -221,9 +221,8 @@ __global__ __launch_bounds__(256) void trsm_base_kernel(const double* __restrict
     trsm_base_body<TRANS, ROWVEC>(sh, L, ldl, nb, B, ldb, ncols, blockIdx.x, dbg);
 }
 
-// (the first-design panel kernel, potrf_panel_kernel, and the contract it introduced -- the LAST workgroup factors A_jj in place, every
-// other workgroup factors its own copy with its 64 rows riding along, load tickets protect the in-place store -- live in
-// dev/gpk_factor_retired.inc; the contract is restated at the kernel below)
+// (the first-design panel kernel of round 1 introduced the contract -- the LAST workgroup factors A_jj in place, every other workgroup
+// factors its own copy with its 64 rows riding along, load tickets protect the in-place store; it is restated at the kernel below)
 
 // ---- Cholesky panel step, second design (round 2): narrow panels factored inside ONE wave, MFMA trailing updates ------------
 // Same contract as potrf_panel_kernel (workgroup 0 factors A_jj in place, workgroup b > 0 factors its own copy and its 64 rows
@@ -855,10 +854,6 @@ __global__ __launch_bounds__(64) void trsv_diag_kernel(const double* __restrict_
     if (lane < nb) x[lane] = res;
 }
 
-#ifdef GPK_DEV
-#include "dev/gpk_factor_retired.inc"   // retired designs (round 1 / 2): potf2 + row-solve launches, first and third panel kernels,
-                                         // persistent outer-block kernel, flag-chained single-vector solve -- development build only
-#endif
 
 // ---- the same solve with DATA-TAGGED hand-offs (round 3) -------------------------------------------------------------------
 // In trsv_fused_kernel a link of the chain costs 4.1 us: x_w goes out as 64 write-through stores, the wave waits for their
@@ -1239,19 +1234,6 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
     // ev_rec_pre: recorded once every panel but the last has been factored (the pipeline starts the next block's update with those)
     if (ob <= 0 || nrows < ob) return 0;
     const int npan = gpk_ceil_div(ob, NB);
-#ifdef GPK_DEV                                                       // retired variant (dev/gpk_factor_retired.inc): development build only
-    if (h->tune.persistent_ob) {
-        if (ev_wait_p1) GPK_HIP(h, hipStreamWaitEvent(h->stream, (hipEvent_t)ev_wait_p1, 0));
-        if (++h->ob_epoch == 0x7fffffff) {
-            GPK_HIP(h, hipMemsetAsync(h->d_obflags, 0, 64 * sizeof(int), h->stream));
-            h->ob_epoch = 1;
-        }
-        potrf_ob_kernel<<<gpk_ceil_div(nrows, NB), 256, 0, h->stream>>>(A, lda, nrows, ob, h->d_obflags, h->ob_epoch, h->d_info, pivot_base, h->tune.dbg);
-        GPK_LAUNCH_CHECK(h);
-        if (ev_rec_pre) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));
-        return 0;
-    }
-#endif
     // FUSED schedule (h->tune.panel_fused, default): the rank-64 work between two panels rides inside the panel kernels (PanelFuse above)
     // Right-looking schedule (whole chip) only: on the 32-CU chain partition of the pipelined phase the product workgroups sit on the
     // same CUs as the panel workgroups and slow them down (co-residence, the very reason for the CU partition): measured 3.13 -> 3.26 ms
@@ -1309,36 +1291,14 @@ int gpk_i_potrf_panel(gpk_handle h, double* A, int nrows, int ob, int lda, int p
             const unsigned target = h->panel_loaded + (unsigned)nrb;
             PanelFuse nofuse;
             memset(&nofuse, 0, sizeof nofuse);
-            bool launched = false;
-#ifdef GPK_DEV                                                       // retired variants (dev/gpk_factor_retired.inc): development build only
-            if (!h->tune.fused_panel) {                              // round 1, before the fused panel step: potf2 + row solve as two launches
-                potf2_kernel<<<1, 256, 0, h->stream>>>(Ajj, lda, nb, h->d_info, pivot_base + j0, h->tune.dbg);
-                if (below > 0)
-                    trsm_base_kernel<false, true><<<gpk_ceil_div(below, NB), 256, 0, h->stream>>>(Ajj, lda, nb, A + (long)(j0 + nb) * lda + j0, lda, below, h->tune.dbg);
-                GPK_LAUNCH_CHECK(h);
-                launched = true;
-            } else if (h->tune.panel_mfma == 2) {                    // third design (factor wave one panel ahead)
-                potrf_panel_la_kernel<<<1 + nrb, 320, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg);
-                GPK_LAUNCH_CHECK(h);
-                h->panel_loaded = target; launched = true;
-            } else if (h->tune.panel_mfma == 0) {                    // first design (two columns per barrier)
-                potrf_panel_kernel<<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                    (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg);
-                GPK_LAUNCH_CHECK(h);
-                h->panel_loaded = target; launched = true;
-            }
-#endif
-            if (!launched) {
-                if (h->tune.panel_unrolled)
-                    potrf_panel_mfma_kernel<8, true><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                      (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, nofuse);
-                else
-                    potrf_panel_mfma_kernel<8, false><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
-                                                                                       (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, nofuse);
-                GPK_LAUNCH_CHECK(h);                                 // a failed launch issues no tickets: count them only now
-                h->panel_loaded = target;
-            }
+            if (h->tune.panel_unrolled)
+                potrf_panel_mfma_kernel<8, true><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                                  (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, nofuse);
+            else
+                potrf_panel_mfma_kernel<8, false><<<1 + nrb, 256, 0, h->stream>>>(Ajj, lda, nb, below, h->d_info, pivot_base + j0,
+                                                                                   (unsigned*)(h->d_flags + GPK_MAX_TRSV_BLOCKS), target, h->tune.dbg, nofuse);
+            GPK_LAUNCH_CHECK(h);                                     // a failed launch issues no tickets: count them only now
+            h->panel_loaded = target;
         }
         if (ev_rec_pre && j0 / NB == npan - 2) GPK_HIP(h, hipEventRecord((hipEvent_t)ev_rec_pre, h->stream));   // (this panel's columns are final)
         if (below > 0 && !left_looking) {
@@ -1700,18 +1660,6 @@ int gpk_i_trsv(gpk_handle h, bool trans, const double* L, int n, int ldl, double
         GPK_LAUNCH_CHECK(h);
         return 0;
     }
-#ifdef GPK_DEV                                                       // retired variant (dev/gpk_factor_retired.inc): the flag-chained form of round 1
-    if (h->tune.fused_trsv && nblk <= GPK_MAX_TRSV_BLOCKS) {
-        if (++h->trsv_epoch == 0x7fffffff) {                         // epoch wrap: clear the flags once every 2^31 solves
-            GPK_HIP(h, hipMemsetAsync(h->d_flags, 0, GPK_MAX_TRSV_BLOCKS * sizeof(int), h->stream));
-            h->trsv_epoch = 1;
-        }
-        if (trans) trsv_fused_kernel<true><<<nblk, 256, 0, h->stream>>>(L, ldl, n, x, h->d_flags, h->trsv_epoch);
-        else       trsv_fused_kernel<false><<<nblk, 256, 0, h->stream>>>(L, ldl, n, x, h->d_flags, h->trsv_epoch);
-        GPK_LAUNCH_CHECK(h);
-        return 0;
-    }
-#endif
     if (!trans) {
         for (int b = 0; b < nblk; ++b) {
             const int r0 = b * NB, nb = (n - r0 < NB) ? n - r0 : NB;

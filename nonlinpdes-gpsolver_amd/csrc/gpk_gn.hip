@@ -371,7 +371,10 @@ int assemble_normal_equations(gpk_handle h, const gpk_gn_problem* p, const Dims&
         gpk_handle h; bool armed; ~SigGuard() { if (armed) h->work_sig[0] = -1; }
     } sig_guard{h, dinv};
     GPK_PROF_MARK(h, 0);
-    GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
+    // (Darcy with the cached a-part: of the a-part rows of S only the F column is read -- build writes it for every row -- so those
+    // 3 N_d rows, a third of the buffer, need not be cleared; the A entries build drops there are never looked at)
+    const long skip = (rev == 4 && dinv && family == 0 && p->Wa && p->Ha) ? d.g[0].n : 0;
+    GPK_HIP(h, hipMemsetAsync(S + skip * lds, 0, (size_t)(d.rows - skip) * lds * sizeof(double), h->stream));
     GPK_TRY(build(h, p, z, S, lds, d.nz, 1, rev, family));
     for (int k = 0; k < d.ngroups; ++k) {
         const Group& g = d.g[k];

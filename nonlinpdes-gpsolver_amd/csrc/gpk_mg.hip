@@ -25,10 +25,17 @@ struct gpk_mg_ctx {
                                            // (exact sizes) on the communication stream with the block-row products of Hb chasing the arrivals,
                                            // -1 (default) = by the bytes each form puts on a link: the shards are cut by WORK, so their widths
                                            // differ (widest / mean = 1.30 / 1.57 / 1.79 at 2 / 4 / 8 ranks of config 5) and the all-gather moves
-                                           // (P - 1) x widest columns per rank against nc columns for the broadcasts (gpk_mg_set_option key 3)
+                                           // (P - 1) x widest columns per rank against nc columns for the broadcasts (gpk_mg_set_option key 3);
+                                           // 2 = DIRECT exchange (round 6): every rank sends its shard to every peer and receives theirs inside
+                                           // one ncclGroupStart / ncclGroupEnd -- exact sizes, and on xGMI (point-to-point links, one per
+                                           // peer) the P - 1 transfers of a rank travel over P - 1 different links at once instead of
+                                           // around a ring; the all-gather of the block rows of Hb takes the same form
     void* comm = nullptr;
     gpk_mg_bcast_fn bcast = nullptr;
     gpk_mg_allgather_fn allgather = nullptr;
+    gpk_mg_send_fn p2p_send = nullptr;     // ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd (optional: the direct exchange, key 3 = 2)
+    gpk_mg_recv_fn p2p_recv = nullptr;
+    gpk_mg_group_fn p2p_begin = nullptr, p2p_end = nullptr;
     bool own_comm = false;
     void* lib = nullptr;
     int (*comm_destroy)(void*) = nullptr;
@@ -158,6 +165,26 @@ int ensure_buffers(gpk_mg_handle mg, size_t panel_bytes) {
     mg->buf_cap = 0;
     for (int i = 0; i < 2; ++i) GPK_HIP(h, hipMalloc((void**)&mg->buf[i], panel_bytes));
     mg->buf_cap = panel_bytes;
+    return 0;
+}
+
+// Exact-size all-to-all of one buffer per rank (the "v" form of an all-gather) through grouped point-to-point calls: rank r's cnt[r]
+// doubles at `send` reach every peer's recv + off[r].  My own part is not moved.  Every rank issues the same group.
+int exchange_direct(gpk_mg_handle mg, const double* send, double* recv, const std::vector<size_t>& cnt, const std::vector<size_t>& off,
+                    hipStream_t s, const char* what) {
+    if (!mg->p2p_send || !mg->p2p_recv || !mg->p2p_begin || !mg->p2p_end)
+        return gpk_bad_arg(mg->h, "gpk_mg: the direct exchange needs ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd (gpk_mg_set_p2p)");
+    const int P = mg->world, me = mg->rank;
+    MG_NCCL(mg, mg->p2p_begin(), what);
+    int r1 = 0;
+    for (int d = 1; d < P && r1 == 0; ++d) {                          // peers in "distance" order: rank me + d receives, rank me - d sends
+        const int to = (me + d) % P, from = (me - d + P) % P;
+        if (cnt[me] > 0) r1 = mg->p2p_send(send, cnt[me], NCCL_DOUBLE, to, mg->comm, (void*)s);
+        if (r1 == 0 && cnt[from] > 0) r1 = mg->p2p_recv(recv + off[from], cnt[from], NCCL_DOUBLE, from, mg->comm, (void*)s);
+    }
+    const int r2 = mg->p2p_end();                                     // (always closed, also after a failed call inside the group)
+    if (r1 != 0) return nccl_fail(mg, r1, what);
+    if (r2 != 0) return nccl_fail(mg, r2, what);
     return 0;
 }
 
@@ -366,12 +393,23 @@ extern "C" int gpk_mg_set_comm(gpk_mg_handle mg, void* comm, gpk_mg_bcast_fn bca
     return 0;
 }
 
+extern "C" int gpk_mg_set_p2p(gpk_mg_handle mg, gpk_mg_send_fn send, gpk_mg_recv_fn recv, gpk_mg_group_fn group_start, gpk_mg_group_fn group_end) {
+    if (!mg || !send || !recv || !group_start || !group_end) return GPK_ERR_ARG;
+    mg->p2p_send = send; mg->p2p_recv = recv; mg->p2p_begin = group_start; mg->p2p_end = group_end;
+    return 0;
+}
+
+extern "C" int gpk_mg_has_p2p(gpk_mg_handle mg) { return (mg && mg->p2p_send && mg->p2p_recv && mg->p2p_begin && mg->p2p_end) ? 1 : 0; }
+
 extern "C" int gpk_mg_set_option(gpk_mg_handle mg, int key, int value) {
     if (!mg) return GPK_ERR_ARG;
     if (key == 0) { mg->lookahead = value != 0; return 0; }
     if (key == 1) { mg->shard_hb = value != 0; return 0; }
     if (key == 2 && value >= 1) { mg->col_align = value; return 0; }
-    if (key == 3 && value >= -1 && value <= 1) { mg->overlap_s = value; return 0; }
+    if (key == 3 && value >= -1 && value <= 2) {
+        if (value == 2 && !gpk_mg_has_p2p(mg)) return gpk_bad_arg(mg->h, "gpk_mg_set_option: key 3 = 2 needs the point-to-point entry points (gpk_mg_set_p2p)");
+        mg->overlap_s = value; return 0;
+    }
     return gpk_bad_arg(mg->h, "gpk_mg_set_option: key / value");
 }
 
@@ -417,6 +455,12 @@ extern "C" int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, cons
     void* comm = nullptr;
     MG_NCCL(mg, init(&comm, mg->world, id, mg->rank), "ncclCommInitRank");
     mg->lib = lib; mg->comm = comm; mg->bcast = bc; mg->allgather = ag; mg->own_comm = true;
+    // optional: the point-to-point entry points of the same library (every RCCL has them; a stand-in library may not)
+    auto sd = (gpk_mg_send_fn)dlsym(lib, "ncclSend");
+    auto rv = (gpk_mg_recv_fn)dlsym(lib, "ncclRecv");
+    auto g0 = (gpk_mg_group_fn)dlsym(lib, "ncclGroupStart");
+    auto g1 = (gpk_mg_group_fn)dlsym(lib, "ncclGroupEnd");
+    if (sd && rv && g0 && g1) { mg->p2p_send = sd; mg->p2p_recv = rv; mg->p2p_begin = g0; mg->p2p_end = g1; }
     return 0;
 }
 
@@ -516,6 +560,39 @@ extern "C" int gpk_mg_preflight(gpk_mg_handle mg, size_t bytes, int reps, double
     return 0;
 }
 
+// The same for the direct exchange (gpk_mg_set_option key 3 = 2): `reps` grouped exchanges in which every rank sends bytes / world to every
+// peer and receives as much from each, after one untimed warm-up.  *host_ms: average milliseconds of one exchange.
+extern "C" int gpk_mg_preflight_p2p(gpk_mg_handle mg, size_t bytes, int reps, double* host_ms) {
+    if (!mg || !host_ms || reps < 1 || bytes < 8) return GPK_ERR_ARG;
+    gpk_handle h = mg->h;
+    if (!gpk_mg_has_p2p(mg)) return gpk_bad_arg(h, "gpk_mg_preflight_p2p: no point-to-point entry points bound");
+    const int P = mg->world;
+    const size_t per = std::max<size_t>(bytes / sizeof(double) / P, 1);
+    double* d = nullptr;
+    GPK_HIP(h, hipMalloc((void**)&d, per * (size_t)(P + 1) * sizeof(double)));
+    std::vector<size_t> cnt((size_t)P, per), off((size_t)P);
+    for (int r = 0; r < P; ++r) off[r] = (size_t)r * per;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(d, 0, per * (size_t)(P + 1) * sizeof(double), h->stream);
+    int rc = e == hipSuccess ? exchange_direct(mg, d + per * P, d, cnt, off, h->stream, "preflight direct exchange") : 0;   // warm-up
+    if (rc == 0 && e == hipSuccess) e = hipEventRecord(e0, h->stream);
+    for (int i = 0; i < reps && rc == 0 && e == hipSuccess; ++i) rc = exchange_direct(mg, d + per * P, d, cnt, off, h->stream, "preflight direct exchange");
+    if (rc == 0 && e == hipSuccess) e = hipEventRecord(e1, h->stream);
+    if (rc == 0 && e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (rc == 0 && e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    *host_ms = (double)ms / reps;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) return gpk_fail(h, e, "gpk_mg_preflight_p2p", __FILE__, __LINE__);
+    return 0;
+}
+
 extern "C" int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info) {
     if (!mg || !A || n < 0 || lda < n) return GPK_ERR_ARG;
     gpk_handle h = mg->h;
@@ -562,7 +639,8 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     //         columns [0, i0 + ib), i.e. the shards up to the one that holds its last column -- its product is issued behind that
     //         shard's event, so the early block rows are computed while the later shards are still travelling.
     const size_t shard = (size_t)rows * per;
-    const bool overlap_s = mg->overlap_s < 0 ? (long)(P - 1) * per > (long)nc : mg->overlap_s != 0;   // (a function of the shapes: all ranks agree)
+    const bool direct = mg->overlap_s == 2;                           // exact sizes, grouped point-to-point (round 6)
+    const bool overlap_s = direct ? true : mg->overlap_s < 0 ? (long)(P - 1) * per > (long)nc : mg->overlap_s != 0;   // (a function of the shapes: all ranks agree; `true` also selects the exact-size packing)
     const int nblk = gpk_ceil_div(nc, nb), per_rank = gpk_ceil_div(nblk, P);
     // the block rows travel as their LOWER parts only (round 4): block row i is ib x (i0 + ib); every rank's share padded to the largest
     std::vector<size_t> share((size_t)P, 0);
@@ -578,7 +656,19 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
         const int i0 = i * nb, ib = std::min(nb, nc - i0);
         return gpk_i_gemm(h, true, false, ib, i0 + ib, rows, 1.0, S2 + i0, lds, S2, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, nz);
     };
-    if (!overlap_s) {
+    if (direct) {
+        std::vector<size_t> cnt((size_t)P), off((size_t)P);
+        size_t o = 0;
+        for (int r = 0; r < P; ++r) { cnt[r] = (size_t)rows * (size_t)(b[r + 1] - b[r]); off[r] = o; o += cnt[r]; }
+        GPK_TRY(exchange_direct(mg, mg->gsend, mg->grecv, cnt, off, s, "direct exchange of the shards of S"));
+        for (int r = 0; r < P; ++r) {
+            const int a0 = b[r], a1 = b[r + 1];
+            if (r == rank || a1 <= a0) continue;
+            GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, mg->grecv + off[r], (size_t)(a1 - a0) * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+                                        hipMemcpyDeviceToDevice, s));
+        }
+        for (int i = rank; i < nblk; i += P) GPK_TRY(block_row(i));
+    } else if (!overlap_s) {
         MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, shard, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of S");
         for (int r = 0; r < P; ++r) {
             const int a0 = b[r], a1 = b[r + 1];
@@ -625,13 +715,21 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
                                         hipMemcpyDeviceToDevice, s));
             o += (size_t)ib * (size_t)(i0 + ib);
         }
-        MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, hshare, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of Hb");
+        std::vector<size_t> hoff((size_t)P);
+        if (direct) {                                                // exact shares, one link per peer
+            size_t acc = 0;
+            for (int r = 0; r < P; ++r) { hoff[r] = acc; acc += share[r]; }
+            GPK_TRY(exchange_direct(mg, mg->gsend, mg->grecv, share, hoff, s, "direct exchange of the block rows of Hb"));
+        } else {
+            for (int r = 0; r < P; ++r) hoff[r] = (size_t)r * hshare;
+            MG_NCCL(mg, mg->allgather(mg->gsend, mg->grecv, hshare, NCCL_DOUBLE, mg->comm, (void*)s), "all-gather of Hb");
+        }
         for (int r = 0; r < P; ++r) {
             if (r == rank) continue;
             size_t oo = 0;
             for (int i = r; i < nblk; i += P) {
                 const int i0 = i * nb, ib = std::min(nb, nc - i0);
-                GPK_HIP(h, hipMemcpy2DAsync(Hb + (long)i0 * ldh, (size_t)ldh * 8, mg->grecv + (size_t)r * hshare + oo, (size_t)(i0 + ib) * 8,
+                GPK_HIP(h, hipMemcpy2DAsync(Hb + (long)i0 * ldh, (size_t)ldh * 8, mg->grecv + hoff[r] + oo, (size_t)(i0 + ib) * 8,
                                             (size_t)(i0 + ib) * 8, (size_t)ib, hipMemcpyDeviceToDevice, s));
                 oo += (size_t)ib * (size_t)(i0 + ib);
             }

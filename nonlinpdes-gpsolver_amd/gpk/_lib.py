@@ -30,12 +30,19 @@ _pp = C.POINTER(GNProblemStruct)
 # collective entry points of include/gpk_mg.h: exactly the signatures of ncclBroadcast / ncclAllGather
 MG_BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
 MG_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)
+# ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd (the direct exchange of the sharded step)
+MG_SEND_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+MG_RECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+MG_GROUP_FN = C.CFUNCTYPE(C.c_int)
 
 # name -> (restype, argtypes); one entry per function of include/gpk.h, include/gpk_mg.h and include/gpk_debug.h
 PROTOTYPES = {
     'gpk_mg_create': (_i, [_vp, _i, _i, _i, _pvp]),
     'gpk_mg_destroy': (_i, [_vp]),
     'gpk_mg_set_comm': (_i, [_vp, _vp, MG_BCAST_FN, MG_ALLGATHER_FN]),
+    'gpk_mg_set_p2p': (_i, [_vp, MG_SEND_FN, MG_RECV_FN, MG_GROUP_FN, MG_GROUP_FN]),
+    'gpk_mg_has_p2p': (_i, [_vp]),
+    'gpk_mg_preflight_p2p': (_i, [_vp, _sz, _i, _pd]),
     'gpk_mg_rccl_probe': (_i, [C.c_char_p, C.c_char_p, _i]),
     'gpk_mg_rccl_unique_id': (_i, [C.c_char_p, _vp]),
     'gpk_mg_rccl_init': (_i, [_vp, C.c_char_p, _vp]),

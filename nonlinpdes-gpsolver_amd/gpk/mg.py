@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from ._lib import GpkError, MG_ALLGATHER_FN, MG_BCAST_FN, load_library
+from ._lib import GpkError, MG_ALLGATHER_FN, MG_BCAST_FN, MG_GROUP_FN, MG_RECV_FN, MG_SEND_FN, load_library
 
 OP_NAMES = {0: 'FACTOR', 1: 'PACK', 2: 'BCAST', 3: 'UNPACK', 4: 'UPDATE', 5: 'RECORD', 6: 'WAIT'}
 FACTOR, PACK, BCAST, UNPACK, UPDATE, RECORD, WAIT = range(7)
@@ -187,8 +187,62 @@ class MultiGpu:
             except Exception:                                     # noqa: BLE001
                 return 3
 
-        self._keep = [MG_BCAST_FN(bcast), MG_ALLGATHER_FN(allgather)]
+        # ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd stand-ins (the direct exchange, set_option('overlap_s', 2)): calls are
+        # queued between group start and group end and carried out there -- wait for the streams, stage the send buffers through host
+        # memory, one isend / irecv per queued call (per pair of ranks at most one of each per group: matched in order), copy the
+        # received buffers back
+        pending = []
+
+        def group_start():
+            pending.clear()
+            pending.append('open')
+            return 0
+
+        def send(buf, count, dtype, peer, comm, stream):
+            if not pending:
+                return 5                                          # (only inside a group here)
+            pending.append(('s', buf, count * _DTYPE_BYTES[dtype], peer, stream))
+            return 0
+
+        def recv(buf, count, dtype, peer, comm, stream):
+            if not pending:
+                return 5
+            pending.append(('r', buf, count * _DTYPE_BYTES[dtype], peer, stream))
+            return 0
+
+        def group_end():
+            try:
+                ops = [o for o in pending if o != 'open']
+                pending.clear()
+                for st in {o[4] for o in ops}:
+                    if hip.hipStreamSynchronize(st) != 0:
+                        return 1
+                reqs, recvs, cache = [], [], {}
+                for kind, buf, nbytes, peer, _ in ops:
+                    if kind == 's':
+                        key = (buf, nbytes)
+                        if key not in cache:                      # (the same shard goes to every peer: staged once)
+                            host = np.empty(nbytes, dtype=np.uint8)
+                            if hip.hipMemcpy(host.ctypes.data, buf, nbytes, 2) != 0:
+                                return 1
+                            cache[key] = torch.from_numpy(host)
+                        reqs.append(dist.isend(cache[key], dst=dist.get_global_rank(group, peer) if group is not None else peer, group=group))
+                    else:
+                        t = torch.empty(nbytes, dtype=torch.uint8)
+                        reqs.append(dist.irecv(t, src=dist.get_global_rank(group, peer) if group is not None else peer, group=group))
+                        recvs.append((buf, t, nbytes))
+                for q in reqs:
+                    q.wait()
+                for buf, t, nbytes in recvs:
+                    if hip.hipMemcpy(buf, t.numpy().ctypes.data, nbytes, 1) != 0:
+                        return 1
+                return 0
+            except Exception:                                     # noqa: BLE001
+                return 3
+
+        self._keep = [MG_BCAST_FN(bcast), MG_ALLGATHER_FN(allgather), MG_SEND_FN(send), MG_RECV_FN(recv), MG_GROUP_FN(group_start), MG_GROUP_FN(group_end)]
         self.ctx._chk(self.lib.gpk_mg_set_comm(self.h, None, self._keep[0], self._keep[1]))
+        self.ctx._chk(self.lib.gpk_mg_set_p2p(self.h, self._keep[2], self._keep[3], self._keep[4], self._keep[5]))
         self.comm_kind = 'host-staged stand-ins over torch.distributed'
 
     # ---- options / calls ----------------------------------------------------------------------------------------------
@@ -211,9 +265,19 @@ class MultiGpu:
         self.ctx._chk(self.lib.gpk_mg_preflight(self.h, int(nbytes), int(reps), bms, C.byref(ams), C.byref(seen)))
         gbs = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else None
         per = max(nbytes // 8 // self.world, 1) * 8
-        return {'bytes': int(nbytes), 'reps': int(reps), 'bcast_ms_by_root': list(bms), 'bcast_gbs_by_root': [gbs(nbytes, m) for m in bms],
-                'allgather_ms': ams.value, 'allgather_gbs_received': gbs(per * (self.world - 1), ams.value) if self.world > 1 else None,
-                'ranks_seen_by_rccl': seen.value}
+        out = {'bytes': int(nbytes), 'reps': int(reps), 'bcast_ms_by_root': list(bms), 'bcast_gbs_by_root': [gbs(nbytes, m) for m in bms],
+               'allgather_ms': ams.value, 'allgather_gbs_received': gbs(per * (self.world - 1), ams.value) if self.world > 1 else None,
+               'ranks_seen_by_rccl': seen.value, 'p2p_bound': self.has_p2p()}
+        if out['p2p_bound'] and self.world > 1:
+            # the direct exchange (grouped ncclSend / ncclRecv): the same bytes per rank as the all-gather above, one transfer per peer
+            pms = C.c_double()
+            self.ctx._chk(self.lib.gpk_mg_preflight_p2p(self.h, int(nbytes), int(reps), C.byref(pms)))
+            out['direct_ms'] = pms.value
+            out['direct_gbs_received'] = gbs(per * (self.world - 1), pms.value)
+        return out
+
+    def has_p2p(self):
+        return bool(self.lib.gpk_mg_has_p2p(self.h))
 
     def potrf(self, A_ptr, n, lda):
         """In-place lower Cholesky over all ranks (A replicated on entry, the full factor on every rank on return) -> info"""

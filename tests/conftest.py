@@ -33,7 +33,7 @@ def golden_dir():
 
 @pytest.fixture(scope='module')
 def dev_ctx():
-    """A handle in libgpk_dev.so -- the development build that also holds the superseded kernel variants (gpk_tune keys 5, 7, 21, 4 = 2),
+    """A handle in libgpk_dev.so -- the development build that also holds the look-ahead factorisation measured in round 5 (gpk_tune key 54),
     the probes and the micro-benchmarks (include/gpk_dev.h).  The product library libgpk.so rejects those keys."""
     import gpk
     c = gpk.Context(0, dev=True)

@@ -201,7 +201,7 @@ def test_bare_command_launches_its_own_ranks(tmp_path):
     assert d['data'].startswith('STUBBED')                        # a stubbed line can never be mistaken for a measurement
     # the host model beside the measurement: per rank count, expected ms of every multi-GPU choice, and the predicted ratio
     for P in ('2', '4', '8'):
-        assert len(d['predicted'][P]['chol']) == 2 and len(d['predicted'][P]['xchg']) == 2 and d['predicted'][P]['x'] > 1
+        assert len(d['predicted'][P]['chol']) == 2 and len(d['predicted'][P]['xchg']) == 3 and d['predicted'][P]['x'] > 1
     assert d['predicted_vs_1gpu'] == pytest.approx(d['predicted']['2']['x'], abs=0.01)
 
 

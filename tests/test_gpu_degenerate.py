@@ -121,12 +121,17 @@ def test_round4_entry_points_reject_bad_arguments_and_handle_edges():
     from oracle import gp_oracle as O
     ctx = gpk.Context(0)
     assert ctx.lib.gpk_tune(ctx.h, 9999, 1) < 0
-    for key, value in ((5, 0), (7, 1), (21, 0), (21, 2), (4, 2), (11, 32)):     # superseded designs: development build only
+    for key, value in ((5, 0), (7, 1), (21, 0), (21, 2), (4, 2)):               # superseded designs of rounds 1-2: removed in round 6
+        assert ctx.lib.gpk_tune(ctx.h, key, value) < 0, (key, value)
+        assert 'removed in round 6' in ctx.lib.gpk_last_error(ctx.h).decode()
+    for key, value in ((11, 32), (54, 1)):                                      # probes / measured-and-not-adopted: development build only
         assert ctx.lib.gpk_tune(ctx.h, key, value) < 0, (key, value)
         assert 'development build' in ctx.lib.gpk_last_error(ctx.h).decode()
     assert ctx.lib.gpk_tune(ctx.h, 21, 1) == 0 and ctx.lib.gpk_tune(ctx.h, 4, 0) == 0 and ctx.lib.gpk_tune(ctx.h, 4, 1) == 0
     dev = gpk.Context(0, dev=True)
-    assert dev.lib.gpk_tune(dev.h, 21, 2) == 0 and dev.lib.gpk_tune(dev.h, 21, 1) == 0      # ... and it has them
+    assert dev.lib.gpk_tune(dev.h, 54, 1) == 0 and dev.lib.gpk_tune(dev.h, 54, 0) == 0      # ... and it has that one
+    assert dev.lib.gpk_tune(dev.h, 21, 2) < 0                                               # the removed designs are gone from both builds
+    assert ctx.lib.gpk_tune(ctx.h, 55, 4) < 0 and ctx.lib.gpk_tune(ctx.h, 55, 1) == 0 and ctx.lib.gpk_tune(ctx.h, 55, 0) == 0   # round 6: store policy 0 .. 3
     dev.close()
     mx, l2 = C.c_double(), C.c_double()
     one = ctx.array(np.array([3.0])); two = ctx.array(np.array([1.0]))

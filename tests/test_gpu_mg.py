@@ -178,7 +178,8 @@ WORKER = textwrap.dedent('''
     assert all(m > 0 for m in pf['bcast_ms_by_root']) and pf['allgather_ms'] > 0 and all(v > 0 for v in pf['bcast_gbs_by_root'])
     mgpu.set_option('col_align', 64)
     results = []
-    for lookahead, shard_hb, overlap_s in ((0, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1)):
+    assert pf['p2p_bound'] and pf['direct_ms'] > 0                 # (round 6) the direct exchange: grouped send / recv stand-ins
+    for lookahead, shard_hb, overlap_s in ((0, 0, 0), (1, 0, 1), (1, 1, 0), (1, 1, 1), (1, 0, 2), (1, 1, 2), (1, 0, -1)):
         mgpu.set_option('lookahead', lookahead)
         mgpu.set_option('shard_hb', shard_hb)
         mgpu.set_option('overlap_s', overlap_s)                   # shards of S: one all-gather / one broadcast per shard, products chasing

@@ -235,9 +235,9 @@ def test_potrf(ctx, n):
     assert np.linalg.norm(L - Lref) <= 1e-11 * np.linalg.norm(Lref)
 
 
-@pytest.mark.parametrize('panel', [1, 2, 3])
+@pytest.mark.parametrize('panel', [1, 3])
 def test_potrf_grid_larger_than_resident(dev_ctx, panel):
-    """(development build: the third design lives in csrc/dev/)  Panel kernels with more workgroups than the chip holds at once (the third design keeps one workgroup per CU: 261 > 256): the
+    """Panel kernels with more workgroups than the chip holds at once (the third design keeps one workgroup per CU: 261 > 256): the
     workgroup that stores the diagonal block waits for the others' load tickets, so it must be one that is dispatched AFTER them (a
     wait for a later workgroup starves when that workgroup is bound to the waiting one's CU).  Checked through sampled entries of L L^T."""
     ctx = dev_ctx
@@ -326,10 +326,10 @@ def test_trsm_dinv(ctx, n, nrhs, lead, block):
         ctx.trsm_dinv(dL, D, dB, dB)                              # aliasing is refused
 
 
-@pytest.mark.parametrize('mode', [1, 2, 0])                       # data-tagged hand-offs (default), flags, two launches per block
+@pytest.mark.parametrize('mode', [1, 0])                          # data-tagged hand-offs (default), two launches per block (the flag-chained form was removed in round 6)
 @pytest.mark.parametrize('n', [1, 64, 100, 1000, 3001])
 def test_trsv_and_potrs(dev_ctx, n, mode):
-    ctx = dev_ctx                                                 # (the flag-chained form, mode 2, exists only in the development build)
+    ctx = dev_ctx
     rng = np.random.RandomState(n)
     A = _spd(rng, n)
     b = rng.normal(size=n)

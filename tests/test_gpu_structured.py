@@ -156,3 +156,25 @@ def test_structured_prepare_argument_checks():
     with pytest.raises(Exception):                                # no structured form of the relaxed system
         gpk.GNProblem(ctx, 'Nonlinear_elliptic_relaxed', Nd, Nb, np.ones(Nd), np.zeros(Nb), T2, p0=1.0, p1=3.0, pen_lambda=1e-4, structured=True)
     ctx.close()
+
+
+@pytest.mark.parametrize('structured', [1, 2])
+def test_in_step_loss_is_the_substituted_loss_in_the_structured_modes(structured):
+    """Round 6 (advisor): the class API takes its loss history from gpk_gn_step's in-step loss.  In the structured / Gram modes that number
+    used to be the mode's own approximate form; it is now the same true substitution gpk_gn_loss performs -- bit for bit -- at every
+    iterate, also near convergence where the approximate forms kept three digits."""
+    import gpk
+    ctx = gpk.Context(0)
+    rng = np.random.RandomState(77)
+    Nd, Nb = 500, 90
+    Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+    f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
+    T, _ = ctx.assemble('Nonlinear_elliptic', 'Gaussian', 0.2, Xd, Xb, 1e-12, 'adaptive')
+    assert ctx.potrf(T) == 0
+    prob = gpk.GNProblem(ctx, 'Nonlinear_elliptic', Nd, Nb, f, g, T, p0=1.0, p1=3.0, structured=structured)
+    z = ctx.array(rng.normal(size=Nd))
+    for _ in range(6):
+        before = ctx.gn_loss(prob, z)
+        loss, info = ctx.gn_step(prob, z)
+        assert info == 0 and loss == before, (loss, before)
+    ctx.close()

@@ -14,7 +14,6 @@ VARIANTS = [
     ('default', {}),
     ('64-row base solves instead of 256-row strips', {3: 0}),
     ('two launches per TRSV block', {4: 0}),
-    ('potf2 + trsm launches per Cholesky panel', {5: 0}),
     ('supertile schedule of the leading-zero SYRK', {6: 1}),
     ('128x128 GEMM tiles', {0: 1}),
     ('128x64 tiles with 8 waves for every launch', {0: 3}),
@@ -22,16 +21,13 @@ VARIANTS = [
     ('128x128 tiles with 16 waves for every launch', {0: 4}),
     ('leading-zero launches in bands of 1 MB of A (every launch banded)', {35: 1, 36: 1}),
     ('no banded tile orders', {35: 0, 36: 0}),
-    ('persistent outer-block Cholesky kernel (flag-chained workgroups)', {7: 1}),
     ('substitution strips instead of the inverted diagonal blocks', {10: 0}),
     ('substitution, 64-row base solves', {10: 0, 3: 0}),
     ('product then right-looking factorisation on one stream (no CU-partition pipeline)', {12: 0}),
     ('right-looking rank-64 updates inside the block columns of the pipelined factorisation', {18: 0}),
     ('pipeline with two pre-fork blocks and a 64-CU chain partition', {17: 2, 13: 64}),
     ('leading-zero products walking K downwards', {16: 1}),
-    ('first-design Cholesky panel kernel (two columns per barrier)', {21: 0}),
     ('second-design panel kernel in its rolled instantiation', {41: 0}),
-    ('third-design Cholesky panel kernel (factor wave one panel ahead; last workgroup stores the diagonal block)', {21: 2}),
     ('Cholesky of Theta on the two-partition pipeline as well', {20: 100000}),
     ('pipelined products without split-K', {24: 0}),
     ('pipelined products with 32-row tiles / with 128-row tiles', {34: 0}),
@@ -68,7 +64,7 @@ def _run(ctx, variant, Xd, Xb, f, g, init, steps, nugget):
 
 
 def test_schedule_variants_agree():
-    # (development build: the list includes the superseded designs of csrc/dev/gpk_factor_retired.inc)
+    # (the superseded designs of rounds 1-2 -- keys 5 = 0, 7 = 1, 21 = 0 / 2, 4 = 2 -- were removed in round 6; both builds reject them)
     import gpk
     ctx = gpk.Context(0, dev=True)
     np.random.seed(5)
@@ -77,6 +73,8 @@ def test_schedule_variants_agree():
     Xd, Xb = sampled_pts_rdm(Nd, Nb, np.array([[0, 1], [0, 1]]))
     f = O.elliptic_rhs(Xd[:, 0], Xd[:, 1]); g = O.elliptic_truth(Xb[:, 0], Xb[:, 1])
     init = np.random.normal(0.0, 1.0, Nd)
+    for k, v in ((5, 0), (7, 1), (21, 0), (21, 2), (4, 2)):
+        assert ctx.lib.gpk_tune(ctx.h, k, v) < 0
     ref_z, ref_hist = _run(ctx, {}, Xd, Xb, f, g, init, 3, 1e-9)
     truth = O.elliptic_truth(Xd[:, 0], Xd[:, 1])
     assert np.sqrt(np.mean((ref_z - truth) ** 2)) < 1e-4
