@@ -70,6 +70,28 @@ class Comm:
         else:
             dist.all_gather_into_tensor(out, t.reshape(-1), group=self.group)
 
+    def exchange_direct(self, parts, mine):
+        """Exact-size all-to-all of one buffer per rank (the direct exchange of the sharded step, gpk_mg.hip exchange_direct): `mine`
+        (contiguous) goes to every peer, parts[r] (contiguous, exactly rank r's size) receives rank r's buffer; parts[self.rank] is not
+        touched.  One batch of point-to-point operations -- over RCCL a single ncclGroupStart / ncclGroupEnd, on xGMI one link per peer."""
+        if self.world == 1:
+            return
+        staged = self._staged(mine)
+        if staged:
+            torch.cuda.current_stream().synchronize()
+        ops = []
+        for d in range(1, self.world):                             # peers in distance order, as the native executor issues them
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            gto = dist.get_global_rank(self.group, to) if self.group is not None else to
+            gfrm = dist.get_global_rank(self.group, frm) if self.group is not None else frm
+            if mine.numel() > 0:
+                ops.append(dist.P2POp(dist.isend, mine, gto, group=self.group))
+            if parts[frm].numel() > 0:
+                ops.append(dist.P2POp(dist.irecv, parts[frm], gfrm, group=self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
     def first_failure(self, info, device):
         """LAPACK info over all ranks: the smallest positive index (every rank saw only the panels it factored); a negative
         value (device-side wait expired) anywhere wins."""
@@ -227,9 +249,11 @@ def _ceil_div(a, b):
 
 
 class ShardedFactorSolve:
-    def __init__(self, ops, comm, nb=512, lookahead=None, shard_hb=None):
+    def __init__(self, ops, comm, nb=512, lookahead=None, shard_hb=None, direct=False):
         """lookahead: None = on for more than one rank; shard_hb: None = the Cholesky of Hb is panel-sharded from 4 ranks on
-        (replicated below: every rank factors its own copy, no communication)."""
+        (replicated below: every rank factors its own copy, no communication); direct: the two exchanges of the step (column shards of S,
+        block rows of Hb) as exact-size point-to-point batches instead of padded all-gathers (round 6; gpk_mg option key 3 = 2)."""
+        self.direct = bool(direct)
         self.ops, self.comm, self.nb = ops, comm, int(nb)
         self.rank, self.P = comm.rank, comm.world
         self.lookahead = (self.P > 1) if lookahead is None else bool(lookahead)
@@ -349,7 +373,19 @@ class ShardedFactorSolve:
                 ops.trsm_left(L, rows, S, c0, c1 - c0)
         if use_dinv:
             S = S2                                                 # the solved block lives in S2 from here on
-        if P > 1:                                                  # all-gather the column shards of S (padded to the widest)
+        if P > 1 and self.direct:                                  # exact sizes, one transfer per peer (no padding to the widest shard)
+            widths = [bounds[r + 1] - bounds[r] for r in range(P)]
+            mine = self._staging('s_send', S, rows * widths[rank]).view(rows, widths[rank])
+            if c1 > c0:
+                mine.copy_(S[:, c0:c1])
+            allp = self._staging('s_recv', S, rows * nc)
+            offs = [rows * bounds[r] for r in range(P)]
+            parts = [allp[offs[r]:offs[r] + rows * widths[r]] for r in range(P)]
+            comm.exchange_direct(parts, mine.reshape(-1))
+            for r in range(P):
+                if r != rank and widths[r] > 0:
+                    S[:, bounds[r]:bounds[r + 1]].copy_(parts[r].view(rows, widths[r]))
+        elif P > 1:                                                # all-gather the column shards of S (padded to the widest)
             mine = self._staging('s_send', S, rows * per).view(rows, per)
             if c1 > c0:
                 mine[:, :c1 - c0].copy_(S[:, c0:c1])
@@ -383,11 +419,16 @@ class ShardedFactorSolve:
                 mine[o:o + ib * (i0 + ib)].view(ib, i0 + ib).copy_(Hb[i0:i0 + ib, :i0 + ib])
                 o += ib * (i0 + ib)
             allp = self._staging('h_recv', Hb, P * hshare)
-            comm.all_gather_into(allp, mine)
+            if self.direct:                                        # exact shares, packed back to back
+                hoff = [sum(share[:r]) for r in range(P)]
+                comm.exchange_direct([allp[hoff[r]:hoff[r] + share[r]] for r in range(P)], mine[:share[rank]])
+            else:
+                hoff = [r * hshare for r in range(P)]
+                comm.all_gather_into(allp, mine)
             for r in range(P):
                 if r == rank:
                     continue
-                o = r * hshare
+                o = hoff[r]
                 for i in range(r, nblk, P):
                     i0, ib = blocks[i]
                     Hb[i0:i0 + ib, :i0 + ib].copy_(allp[o:o + ib * (i0 + ib)].view(ib, i0 + ib))

@@ -98,7 +98,12 @@ def _worker(rank, world, port, case, out_dir):
             delta = torch.zeros(nz, dtype=torch.float64)
             sol_ref, hist_ref = O.gn_method(sysm, [O.cholesky(Theta)], z0, 3, 1)
             Dinv = solver.ops.trtri_diag(Lt, N, block=32)         # (the test double takes any block size)
-            for rev, dinv in ((False, False), (True, False), (False, True), (True, True)):   # plain / leading-zero layout, substitution / inverted blocks
+            # plain / leading-zero layout, substitution / inverted blocks; round 6: padded all-gathers / the DIRECT exchange (exact-size
+            # point-to-point batches, what gpk_mg option key 3 = 2 does over ncclSend / ncclRecv) -- same numbers, the exchange moves bits
+            finals = {}
+            for rev, dinv, direct in ((False, False, False), (True, False, False), (False, True, False), (True, True, False),
+                                      (True, True, True), (False, False, True)):
+                solver.direct = direct
                 z = torch.from_numpy(z0.copy())
                 S2 = torch.zeros_like(S) if dinv else None
                 hist = []
@@ -108,6 +113,10 @@ def _worker(rank, world, port, case, out_dir):
                     hist.append(loss_in)
                 np.testing.assert_allclose(hist, hist_ref[:3], rtol=1e-7)
                 assert np.linalg.norm(z.numpy() - sol_ref) <= 1e-7 * np.linalg.norm(sol_ref)
+                finals[(rev, dinv, direct)] = z.numpy().copy()
+            assert np.array_equal(finals[(True, True, True)], finals[(True, True, False)])      # the exchange form does not change a bit
+            assert np.array_equal(finals[(False, False, True)], finals[(False, False, False)])
+            solver.direct = False
             np.save(os.path.join(out_dir, f'gn_{rank}.npy'), z.numpy())
             if case == 'gn':
                 b = solver.column_ranges_lz(nz + 1, nz, N)        # work-balanced shards: monotone, cover everything
