@@ -378,23 +378,30 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
 
     # The one-time phases once more, WARM (round 6): the measurements above are the first launches of the process (clocks still ramping,
     # pages and TLBs cold -- tools/assembly_store_ab.py: the same evaluator launch takes 0.112 ms there and 0.088 ms in steady state).  A
-    # roofline fraction is about the kernel, so it is taken from launches issued AFTER the timed steps: 10 assemblies and 3 factorisations
-    # into a scratch matrix, min and median reported; the first-call figures stay in one_time_ms.
+    # roofline fraction is about the kernel, so it is taken from launches issued AFTER the timed steps: 8 assemblies (mean launch duration; min and
+    # median beside it) and 3 factorisations into a scratch matrix; the first-call figures stay in one_time_ms.
     asm_cold_ms, chol_cold_ms = asm_kernel_ms, chol_ms
     T2 = ctx.empty(N, N)
     ctx.prof_enable(True)
     asm_warm = []
-    for _ in range(10):
+    for _ in range(8):                                            # 8 launches, each alone on the chip (host round trip in between)
         ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, dXd.ptr, Nd, dXb.ptr, Nb, nugget, 2, T2.ptr, T2.ld, ratios))
         ctx.synchronize()
         asm_warm.append(ctx.prof_read_assembly())
     ctx.prof_enable(False)
+    # ... and 8 calls back to back (point packing + evaluator each): the SUSTAINED write rate.  A launch that runs alone ends while up to
+    # 256 MB of its 8 N^2 bytes still sit in the Infinity Cache; behind another write stream it has to wait for that one's write-back
+    # (config 2: 0.088-0.100 ms alone, 0.113 ms in a row; at config 5, 9.2 GB, the two agree: 5.6 TB/s)
+    ctx.synchronize(); ctx.timer_start()
+    for _ in range(8):
+        ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, dXd.ptr, Nd, dXb.ptr, Nb, nugget, 2, T2.ptr, T2.ld, ratios))
+    asm_row_ms = ctx.timer_stop() / 8.0
     chol_warm = []
     for _ in range(3):
         ctx._chk(ctx.lib.gpk_assemble(ctx.h, 0, 0, kp, dXd.ptr, Nd, dXb.ptr, Nb, nugget, 2, T2.ptr, T2.ld, ratios))
         ctx.timer_start(); ctx.potrf(T2); chol_warm.append(ctx.timer_stop())
     T2.free()
-    asm_kernel_ms, chol_ms = min(asm_warm), min(chol_warm)
+    asm_kernel_ms, chol_ms = float(np.mean(asm_warm)), min(chol_warm)     # (assembly: the AVERAGE launch duration, as rocprofv3 --stats reports it)
 
     # accuracy half of the metric
     sol = z.download()
@@ -489,12 +496,13 @@ def run_single(args, workload, comm=None, secondary=False, steps=None, warmup=No
         'roofline_assembly': {'bound': 'hbm', 'kernel': 'assemble2_kernel<elliptic> (the Gram evaluator launch itself)',
                               'achieved': 8.0 * N * N / (asm_kernel_ms * 1e-3) / 1e9,
                               'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': 8.0 * N * N / (asm_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              'bytes_per_launch': 8.0 * N * N, 'kernel_ms': asm_kernel_ms, 'kernel_ms_median': float(np.median(asm_warm)),
+                              'bytes_per_launch': 8.0 * N * N, 'kernel_ms': asm_kernel_ms, 'kernel_ms_min': min(asm_warm), 'kernel_ms_median': float(np.median(asm_warm)),
+                              'sustained_call_ms': asm_row_ms, 'sustained_gbs': 8.0 * N * N / (asm_row_ms * 1e-3) / 1e9,
                               'kernel_ms_first_launches': asm_cold_ms, 'launches_timed': len(asm_warm),
                               'store_policy': 'plain global_store_dwordx4 (A/B of nt / sc0 sc1 / sc0 sc1 nt: profiles/r06_assembly_store_ab.json -- nt is 15-20 % slower)',
                               'call_ms': asm_ms, 'call_gbs': 8.0 * N * N / (asm_ms * 1e-3) / 1e9,
                               'note': 'achieved = 8 N^2 bytes written / duration of the evaluator launch (HIP events around that launch on its '
-                                      'stream), the fastest of launches_timed launches issued after the timed steps (kernel_ms_median beside it; '
+                                      'stream), MEAN over launches_timed launches issued one at a time after the timed steps (kernel_ms_min / _median beside it; sustained_gbs = 8 calls back to back incl. point packing; '
                                       'kernel_ms_first_launches = the same at process start, clocks and pages cold); call_ms = the whole gpk_assemble call (point packing kernel + launch overheads) by events around the call'},
         # the factorisation of Theta (north star: "MFMA fp64 utilisation for the factorisation"): N^3/3 flops are what a Cholesky
         # executes (nothing structural to skip) over the whole gpk_potrf call -- panel kernels, rank-64 updates and the trailing

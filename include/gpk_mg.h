@@ -93,7 +93,8 @@ int gpk_mg_preflight_p2p(gpk_mg_handle mg, size_t bytes, int reps, double* host_
  * lower factor on every rank on return.  host_info: LAPACK info, identical on all ranks (one host read at the end). */
 int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info);
 
-/* gpk_gn_step over all ranks (elliptic system; host_prob->L = the replicated factor, host_prob->Dinv/dinv_block = its
+/* gpk_gn_step over all ranks (elliptic system and, since round 6, the Eikonal and Burgers systems -- one factor each, the same column
+ * shards cut by work under their own leading-zero profiles; Darcy and the relaxed system: one GPU only; host_prob->L = the replicated factor, host_prob->Dinv/dinv_block = its
  * inverted diagonal blocks, gpk_trtri_diag).  S, S2: s_rows x lds each; S2 must be ZERO before the first step and is then
  * reused across steps (the solve never writes left of the leading-zero boundary).  z is updated identically on every rank.
  * world == 1: the call is gpk_gn_step itself (S2 unused), bit for bit. */

@@ -177,6 +177,7 @@ struct gpk_ctx {
                                     // launch that is given a non-zero `lead`); stair_col0 / stair_row0: global column of the launch's column 0 and
                                     // global row of its k = 0, set by the caller around each gpk_i_gemm call
     int stair_col0 = 0, stair_row0 = 0;
+    int stair_base = 0;             // gpk_i_trsm_left_dinv with a piecewise profile: global column of ITS column 0 (a column shard of the sharded step)
     int lead_div = 1;               // slope of the leading-zero staircase while a Gauss-Newton step is being issued: column c of the
                                     // right-hand side is zero above row (lead-1-c) / lead_div (1: elliptic, Eikonal; 3: Burgers)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // column-group streams of the multi-RHS triangular solve
@@ -241,6 +242,13 @@ int gpk_i_dot(gpk_handle h, const double* x, const double* y, int n, double* d_o
 int gpk_i_ensure_points(gpk_handle h, size_t doubles);
 // pieces of the Gauss-Newton step used by the multi-GPU schedule (gpk_gn.hip)
 int gpk_i_gn_dims(gpk_handle h, const gpk_gn_problem* p, int* nz, int* rows);
+// the column layout gpk_gn_step runs a system in (1 elliptic, 2 Eikonal, 3 Burgers, 4 Darcy, 0 dense) and the handle state that goes with it for
+// one call (Eikonal: its two-segment profile in gpk_ctx::stair; Burgers: lead_div = 3); leave resets it.  first_row: the first row of column c
+// (storage order, c < nz) that can be non-zero under the layout entered
+int gpk_i_gn_layout(gpk_handle h, const gpk_gn_problem* p);
+void gpk_i_gn_layout_enter(gpk_handle h, const gpk_gn_problem* p, int rev);
+void gpk_i_gn_layout_leave(gpk_handle h);
+int gpk_i_gn_first_row(gpk_handle h, int nz, int c);
 int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double** d_out);   // gpk_tune key 52: loss(z) by substitution on h->stream
 int gpk_i_gn_finish(gpk_handle h, const gpk_gn_problem* p, int nz, int rev, const double* Hb, int ldh, double* scratch, double* delta,
                     double* z, double step_size);

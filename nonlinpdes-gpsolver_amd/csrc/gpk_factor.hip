@@ -1122,12 +1122,13 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
     // piecewise profile (gpk_ctx::stair, Darcy): columns and rows are those of this call's top level (column 0 of B, row 0 of L); every
     // product below is told where its column 0 / its k = 0 lie in that frame, and `lead` only says "there is a profile"
     const bool pw = lead > 0 && h->stair.nseg > 0;
-    int clo = pw ? gpk_stair_first_col(h->stair, row0 + n, nrhs) : lead - sd * (row0 + n);   // (lead = 0: dense right-hand sides)
+    const int base = pw ? h->stair_base : 0;                         // (round 6: B's column 0 is column `base` of the profile's frame -- a column shard)
+    int clo = pw ? gpk_stair_first_col(h->stair, row0 + n, base + nrhs) - base : lead - sd * (row0 + n);   // (lead = 0: dense right-hand sides)
     clo = clo > 0 ? (clo / NB) * NB : 0;
     if (clo >= nrhs) return 0;
     if (n <= db) {
         const int lz = pw ? 1 : lead - sd * row0 - clo;
-        h->stair_col0 = clo; h->stair_row0 = row0;
+        h->stair_col0 = base + clo; h->stair_row0 = row0;
         return gpk_i_gemm(h, false, false, n, nrhs - clo, n, 1.0, Dinv + (long)row0 * db, db, B + clo, ldb, 0.0, X + clo, ldx,
                           false, lz > 0 ? lz : 0, true);
     }
@@ -1136,11 +1137,11 @@ int gpk_i_trsm_left_dinv(gpk_handle h, const double* L, const double* Dinv, int 
     const int n2 = n - n1;
     const double* L21 = L + (long)n1 * ldl;
     GPK_TRY(gpk_i_trsm_left_dinv(h, L, Dinv, db, n1, ldl, B, ldb, X, ldx, nrhs, lead, row0));
-    int c1 = pw ? gpk_stair_first_col(h->stair, row0 + n1, nrhs) : lead - sd * (row0 + n1);   // X[rows of part 1] is zero left of this column
+    int c1 = pw ? gpk_stair_first_col(h->stair, row0 + n1, base + nrhs) - base : lead - sd * (row0 + n1);   // X[rows of part 1] is zero left of this column
     c1 = c1 > 0 ? (c1 / NB) * NB : 0;
     if (c1 < nrhs) {
         const int lz = pw ? 1 : lead - sd * row0 - c1;
-        h->stair_col0 = c1; h->stair_row0 = row0;
+        h->stair_col0 = base + c1; h->stair_row0 = row0;
         if (h->tune.solve_splitk && gpk_i_splitk_reserve(h) == 0) {
             // launches that fill the chip badly (a fraction of a wave, or 1.2 waves): more, shorter workgroups (split-K)
             const long t64 = (long)gpk_ceil_div(n2, 64) * gpk_ceil_div(nrhs - c1, 64);

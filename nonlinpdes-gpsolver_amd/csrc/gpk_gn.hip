@@ -323,11 +323,8 @@ int step_layout(gpk_handle h, const gpk_gn_problem* p) {
 // the staircase slope of the Burgers system; everything reset on the way out, whichever way that is.
 struct LayoutScope {
     gpk_handle h;
-    LayoutScope(gpk_handle hh, const gpk_gn_problem* p, int rev) : h(hh) {
-        if (rev == 2 && h->tune.use_dinv && p->Dinv && p->dinv_block > 0 && h->tune.eikonal_lz != 2) h->stair = eikonal_profile(p->Nd);
-        h->lead_div = rev == 3 ? 3 : 1;
-    }
-    ~LayoutScope() { h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0; h->lead_div = 1; }
+    LayoutScope(gpk_handle hh, const gpk_gn_problem* p, int rev) : h(hh) { gpk_i_gn_layout_enter(h, p, rev); }
+    ~LayoutScope() { gpk_i_gn_layout_leave(h); }
     LayoutScope(const LayoutScope&) = delete;
 };
 
@@ -914,13 +911,15 @@ extern "C" int gpk_gn_build(gpk_handle h, const gpk_gn_problem* p, const double*
 
 extern "C" int gpk_gn_build_rev(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, int lds) {
     if (!h || !z || !S || !p) return GPK_ERR_ARG;
-    if (p->system != GPK_GN_ELLIPTIC) return gpk_bad_arg(h, "gn_build_rev: elliptic system only");
+    // (round 6: also the Eikonal and Burgers systems in the staircase orders of their gpk_gn_step -- the sharded step uses them)
+    const int rev = step_layout(h, p);
+    if (rev < 1 || rev > 3 || p->system == GPK_GN_ELLIPTIC_RELAXED) return gpk_bad_arg(h, "gn_build_rev: elliptic, Eikonal and Burgers systems only");
     Dims d;
     gpk_gn_problem q = *p;
     if (gn_dims(&q, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
     if (lds < d.nz + 1) return gpk_bad_arg(h, "gn: lds < nz+1");
     GPK_HIP(h, hipMemsetAsync(S, 0, (size_t)d.rows * lds * sizeof(double), h->stream));
-    return build(h, &q, z, S, lds, d.nz, 1, 1);
+    return build(h, &q, z, S, lds, d.nz, 1, rev);
 }
 
 extern "C" int gpk_axpy(gpk_handle h, int n, double alpha, const double* x, double* y) {
@@ -950,7 +949,20 @@ int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, 
     return 0;
 }
 
-// n_z and the row count of the elliptic system handled by the sharded step
+int gpk_i_gn_layout(gpk_handle h, const gpk_gn_problem* p) { return step_layout(h, p); }
+void gpk_i_gn_layout_enter(gpk_handle h, const gpk_gn_problem* p, int rev) {
+    if (rev == 2 && h->tune.use_dinv && p->Dinv && p->dinv_block > 0 && h->tune.eikonal_lz != 2) h->stair = eikonal_profile(p->Nd);
+    h->lead_div = rev == 3 ? 3 : 1;
+}
+void gpk_i_gn_layout_leave(gpk_handle h) { h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0; h->stair_base = 0; h->lead_div = 1; }
+int gpk_i_gn_first_row(gpk_handle h, int nz, int c) {
+    if (c >= nz) return 0;                                           // the F column is dense
+    if (h->stair.nseg > 0) return gpk_stair_min(h->stair, c, c + 1);
+    const int sd = h->lead_div > 0 ? h->lead_div : 1;
+    return (nz - 1 - c) / sd;
+}
+
+// n_z and the row count of the system handled by the sharded step
 int gpk_i_gn_dims(gpk_handle h, const gpk_gn_problem* p, int* nz, int* rows) {
     Dims d;
     GPK_TRY(check_prob(h, p, d));

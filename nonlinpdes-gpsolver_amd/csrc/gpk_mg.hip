@@ -124,6 +124,31 @@ void make_plan(int n, int nb, int P, int r, int lookahead, std::vector<Op>& ops)
     if (P > 1) ops.push_back({GPK_MG_WAIT, EB(nblk - 1), 0, M});
 }
 
+// the same rule for any leading-zero layout: column c costs (rows - first_row(c))^2 (round 6: the Burgers and Eikonal systems)
+template <class FirstRow>
+void column_bounds_by(int ncols, int rows, int P, int align, FirstRow first_row, std::vector<int>& b) {
+    b.assign(1, 0);
+    if (align < 1) align = 1;
+    std::vector<double> w((size_t)std::max(ncols, 0));
+    double acc = 0.0;
+    for (int c = 0; c < ncols; ++c) {
+        const double len = (double)rows - (double)std::max(0, first_row(c));
+        acc += len * len;
+        w[c] = acc;
+    }
+    for (int r = 1; r < P; ++r) {
+        int cut = 0;
+        if (ncols > 0) {
+            const double target = w[ncols - 1] * r / P;
+            cut = (int)(std::lower_bound(w.begin(), w.end(), target) - w.begin());
+        }
+        cut = gpk_ceil_div(cut, align) * align;
+        cut = std::min(std::max(cut, b.back()), ncols);
+        b.push_back(cut);
+    }
+    b.push_back(ncols);
+}
+
 void column_bounds(int ncols, int lead, int rows, int P, int align, std::vector<int>& b) {
     // mirrors gpk/sharded.py::column_ranges_lz (numpy cumsum + searchsorted(side='left')); all values are integers < 2^53
     b.assign(1, 0);
@@ -611,8 +636,16 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     gpk_handle h = mg->h;
     const int P = mg->world, rank = mg->rank, nb = mg->nb;
     if (P == 1) return gpk_gn_step(h, p, z, step_size, S, lds, Hb, ldh, delta, host_loss_in, host_info);
-    if (p->system != GPK_GN_ELLIPTIC) return gpk_bad_arg(h, "gpk_mg_gn_step: elliptic system only");
+    // round 6: the Eikonal and Burgers systems as well (one factor each), in the staircase orders of their gpk_gn_step; Darcy (two factors
+    // with different column supports) and the relaxed system are one-GPU only
+    const int rev = gpk_i_gn_layout(h, p);
+    if ((p->system != GPK_GN_ELLIPTIC && p->system != GPK_GN_EIKONAL && p->system != GPK_GN_BURGERS) || rev < 1 || rev > 3)
+        return gpk_bad_arg(h, "gpk_mg_gn_step: elliptic, Eikonal and Burgers systems only (leading-zero layout)");
     if (!p->Dinv || !S2) return gpk_bad_arg(h, "gpk_mg_gn_step: needs the inverted diagonal blocks (Dinv) and S2");
+    struct LayoutGuard {                                             // Eikonal: its profile in the handle; Burgers: the slope; reset on every way out
+        gpk_handle h; LayoutGuard(gpk_handle hh, const gpk_gn_problem* pp, int r) : h(hh) { gpk_i_gn_layout_enter(h, pp, r); }
+        ~LayoutGuard() { gpk_i_gn_layout_leave(h); }
+    } layout_guard(h, p, rev);
     if (!mg->allgather) return gpk_bad_arg(h, "gpk_mg: world > 1 needs a communicator (gpk_mg_rccl_init / gpk_mg_set_comm)");
     int nz = 0, rows = 0;
     GPK_TRY(gpk_i_gn_dims(h, p, &nz, &rows));
@@ -625,13 +658,18 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     if (h->tune.exact_loss) GPK_TRY(gpk_i_gn_exact_loss(h, p, z, &d_exact));
     // ---- S <- [A | F] in the leading-zero layout on every rank (a memset + O(N)); my column shard of L^{-1}[A | F] -> S2
     GPK_TRY(gpk_gn_build_rev(h, p, z, S, lds));
-    column_bounds(nc, nz, rows, P, mg->col_align, mg->bounds);
+    if (rev == 1) column_bounds(nc, nz, rows, P, mg->col_align, mg->bounds);
+    else column_bounds_by(nc, rows, P, mg->col_align, [&](int c) { return gpk_i_gn_first_row(h, nz, c); }, mg->bounds);
     const std::vector<int>& b = mg->bounds;
     const int c0 = b[rank], c1 = b[rank + 1];
     int per = 0;
     for (int r = 0; r < P; ++r) per = std::max(per, b[r + 1] - b[r]);
-    if (c1 > c0)
-        GPK_TRY(gpk_i_trsm_left_dinv(h, p->L, p->Dinv, db, rows, p->ldl, S + c0, lds, S2 + c0, lds, c1 - c0, std::max(nz - c0, 0), 0));
+    if (c1 > c0) {
+        h->stair_base = c0;                                          // (piecewise profile: my shard's column 0 in the profile's frame)
+        const int rc = gpk_i_trsm_left_dinv(h, p->L, p->Dinv, db, rows, p->ldl, S + c0, lds, S2 + c0, lds, c1 - c0, std::max(nz - c0, 0), 0);
+        h->stair_base = 0; h->stair_col0 = h->stair_row0 = 0;        // (the products below read S2 from its column 0, row 0)
+        GPK_TRY(rc);
+    }
     // ---- exchange of the column shards of S2, then my block rows (cyclic) of the lower triangle of Hb = S2^T S2 (structural zeros
     //      skipped).  Two forms of the exchange (gpk_mg_set_option key 3; bench.py times both on the fabric and keeps the faster):
     //      0: ONE all-gather (shards padded to the widest; persistent staging buffers), products afterwards;
@@ -742,7 +780,7 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
     if (mg->shard_hb) GPK_TRY(exec_potrf(mg, Hb, nc, ldh));
     else GPK_TRY(gpk_i_potrf(h, Hb, nc, ldh, 0));
-    GPK_TRY(gpk_i_gn_finish(h, p, nz, 1, Hb, ldh, S, delta, z, step_size));
+    GPK_TRY(gpk_i_gn_finish(h, p, nz, rev, Hb, ldh, S, delta, z, step_size));
     double loss = 0.0;
     int info = 0;
     GPK_HIP(h, hipMemcpyAsync(&loss, d_exact ? d_exact : d_loss, sizeof(double), hipMemcpyDeviceToHost, s));

@@ -9,6 +9,16 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# One ROCm stack per process: torch wheels bundle their own libamdhip64 / librccl, and whichever of torch and
+# libgpk.so is loaded FIRST decides which HIP runtime the process runs on.  bench.py and the drivers load torch first; so does every test
+# session, whatever subset of files it runs -- a session that opened libgpk.so (system ROCm), bound the system librccl in-process
+# (tests/test_gpu_mg.py::test_rccl_binding_comes_up_with_one_rank) and only THEN imported torch ended with two runtimes and a double free at
+# interpreter exit (round 6: `pytest tests/test_gpu_mg.py tests/test_gpu_sharded_ops.py`; the full suite never did, an earlier file imports torch).
+try:
+    import torch  # noqa: F401,E402
+except Exception:                                                 # noqa: BLE001 -- CPU-only tiers without torch still collect
+    pass
+
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 REFERENCE = '/root/reference'          # exists only in the authoring container, never on the GPU box
 

@@ -76,6 +76,27 @@ def _steps_against_oracle(ctx, prob, sysm, Ls_host, z0, steps, name, loss_rtol=1
     return worst
 
 
+def _structured_map_matches(ctx, prob, sprob, z0, steps, name, tol=1e-7):
+    """Round 6: the optional structured solve (gpk_gn_structured_prepare: L^{-1}A(z) = W1 diag(d(z)) + W2) as a MAP, step by step along the
+    default path's trajectory at FULL size: from the same iterate the structured step and the per-step solve must land within `tol` of each
+    other (the per-step solve is within 1e-6 of the oracle at every one of these iterates: _steps_against_oracle above), same in-step loss."""
+    z = ctx.array(z0)
+    worst = 0.0
+    for it in range(steps):
+        zs = ctx.array(z.download())
+        loss_d, info_d = ctx.gn_step(prob, z, 1.0)
+        loss_s, info_s = ctx.gn_step(sprob, zs, 1.0)
+        assert info_d == 0 and info_s == 0
+        r = _rel(zs.download(), z.download())
+        worst = max(worst, r)
+        assert r <= tol, (name, it, r)
+        assert loss_s == pytest.approx(loss_d, rel=1e-9)          # both by true substitution from the same iterate
+        zs.free()
+    print(f'[{name}] structured step vs per-step solve over {steps} steps of the trajectory: worst iterate rel. dev {worst:.2e}')
+    z.free()
+    return worst
+
+
 # ------------------------------------------------------------------------------------------------ BASELINE config 2
 @pytest.fixture(scope='module')
 def c2(ctx):
@@ -168,7 +189,9 @@ def test_config3_burgers_against_oracle(ctx):
     prob = gpk.GNProblem(ctx, 'Burgers', Nd, Nb, np.zeros(Nd), bdy, T, p0=1.0, p1=0.02)
     sysm = O.BurgersSystem(1.0, 0.02, np.zeros(Nd), bdy)
     _steps_against_oracle(ctx, prob, sysm, [L], z0, 8, 'C3')           # all eight steps of the reference configuration
-    prob.release_workspace(); T.free()
+    sprob = gpk.GNProblem(ctx, 'Burgers', Nd, Nb, np.zeros(Nd), bdy, T, p0=1.0, p1=0.02, structured=True)
+    _structured_map_matches(ctx, prob, sprob, z0, 8, 'C3')
+    sprob.release_workspace(); prob.release_workspace(); T.free()
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE config 4
@@ -200,7 +223,10 @@ def test_config4_darcy_against_oracle(ctx):
     prob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, f, g, Tu, p0=noise, data_u=data, L2=Ta)
     sysm = O.DarcySystem(f, g, data, noise)
     _steps_against_oracle(ctx, prob, sysm, [La, Lu], z0, 8, 'C4')     # all eight steps of the reference configuration
-    prob.release_workspace(); Tu.free(); Ta.free()
+    assert prob.Wa is not None                                        # (the default: the iteration-independent a-part cached, bit-identical)
+    sprob = gpk.GNProblem(ctx, 'Darcy_flow2d', Nd, Nb, f, g, Tu, p0=noise, data_u=data, L2=Ta, structured=True)
+    _structured_map_matches(ctx, prob, sprob, z0, 8, 'C4')
+    sprob.release_workspace(); prob.release_workspace(); Tu.free(); Ta.free()
 
 
 # ------------------------------------------------------------------------------------------------ north-star size

@@ -22,7 +22,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 # the value's workload alone (config 2): per-kernel averages here are directly comparable with bench.py's roofline object
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c2 -- python3 $REPO/bench.py $ONE > $OUT/bench_c2_under_rocprof.json 2> $OUT/stats_c2.err
 for wl in c3 c4; do
-    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $REPO/bench.py --workload $wl --no-cpu-baseline > $OUT/bench_${wl}_under_rocprof.json 2> $OUT/stats_$wl.err
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $REPO/bench.py --workload $wl --no-cpu-baseline --no-structured > $OUT/bench_${wl}_under_rocprof.json 2> $OUT/stats_$wl.err
 done
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
     name=$(echo $pass | tr ' ' '+')
@@ -37,7 +37,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
 done
 # BASELINE configs 3, 4 and 5-on-one-GPU: the same four PMC passes (round 5: no roofline.traffic of the line stays null)
 for wl in c3 c4 c5; do
-    EXTRA="--no-cpu-baseline"; [ $wl = c5 ] && EXTRA="--no-cpu-baseline --no-sharded-parity"
+    EXTRA="--no-cpu-baseline --no-structured"; [ $wl = c5 ] && EXTRA="--no-cpu-baseline --no-sharded-parity"
     [ $wl = c5 ] && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $REPO/bench.py --workload $wl $EXTRA --steps 2 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2> $OUT/stats_$wl.err
     for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
         name=$(echo $pass | tr ' ' '+')
