@@ -883,8 +883,25 @@ def run_system(args, workload, steps=None, warmup=None):
                 'f1_equivalent_steps_per_s': steps / el_s, 'f1_flops_per_step': dense,
                 'iterate_rel_diff_vs_default': float(np.linalg.norm(sol_s - sol) / np.linalg.norm(sol))},
                 'note': 'optional mode, not the reference operation sequence per step; next to, never instead of, the value above'}
+            zs.free()
+            # second level (gpk_gn_gram_prepare): the bordered matrix assembled from the Gram blocks of W1, W2 in O(n_z^2) per step --
+            # neither the solve of A(z) nor the product S^T S runs; the F column is still solved, the Cholesky of H unchanged
+            ctx.synchronize(); t0 = time.perf_counter()
+            sp.prepare_gram()
+            ctx.synchronize(); gram_setup = 1e3 * (time.perf_counter() - t0)
+            zs = ctx.array(z0)
+            for _ in range(warmup):
+                ctx.gn_step(sp, zs)
+            ctx.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                ctx.gn_step(sp, zs)
+            ctx.synchronize(); el_g = time.perf_counter() - t0
+            sol_g = zs.download()
+            out['structured_step']['gram_level'] = {
+                'value': steps / el_g, 'unit': 'GN steps/s', 'ms_per_step': 1e3 * el_g / steps, 'setup_ms': sp.structured_prepare_ms + gram_setup,
+                'iterate_rel_diff_vs_default': float(np.linalg.norm(sol_g - sol) / np.linalg.norm(sol))}
             zs.free(); sp.release_workspace()
-            for a_ in (sp.W1, sp.W2, sp.v0, sp.Dinv, sp.Dinv2, sp.Wa, sp.Ha):
+            for a_ in (sp.W1, sp.W2, sp.v0, sp.G, sp.pvec, sp.Dinv, sp.Dinv2, sp.Wa, sp.Ha):
                 if a_ is not None:
                     a_.free()
         except Exception as e:                                    # noqa: BLE001 -- reported, the workload's value survives

@@ -140,6 +140,8 @@ def compact_secondary(o):
     if isinstance(st, dict):                                        # optional structured solve of this workload: ms, one-time cost, agreement
         lv = st.get('solve_level')
         out['structured'] = pick(lv, ('ms_per_step', 'setup_ms', 'iterate_rel_diff_vs_default')) if isinstance(lv, dict) else {'error': short(str(st.get('error')), 120)}
+        if isinstance(st.get('gram_level'), dict):
+            out['structured']['gram'] = pick(st['gram_level'], ('ms_per_step', 'setup_ms', 'iterate_rel_diff_vs_default'))
     for k in ('error', 'fallback'):
         if k in o:
             out[k] = short(o[k], 160)

@@ -224,7 +224,12 @@ int gpk_gn_structured_prepare(gpk_handle h, const gpk_gn_problem* host_prob, dou
  *   H/2 = D G11 D + D G12 + G21 D + G22,   g/2 = D q1 + q2,   loss = v0^T v0 + a.p1 + z.p2 + a.q1 + z.q2
  *   (D = diag(alpha m z^(m-1)), a = alpha z^m, q1 = G11 a + G12 z + p1, q2 = G21 a + G22 z + p2),
  * in O(nz^2) memory-bound work per step: neither the triangular solve nor the product S^T S is executed; the Cholesky
- * factorisation of H, the solve and the update are unchanged.  Same iterates up to rounding (tests/test_gpu_structured.py). */
+ * factorisation of H, the solve and the update are unchanged.  Same iterates up to rounding (tests/test_gpu_structured.py).
+ * Burgers / Eikonal / Darcy (round 6; host_prob carries the W1, W2 of their structured form, A(z) = A1 diag(d(z)) + A2): the same four
+ * blocks; per step  H/2 = D G11 D + D G12 + G21 D + G22  with D = diag(d(z)), and the border from the column w = L^{-1}F(z), which is
+ * SOLVED every step (one column per factor):  g/2 = D W1^T w + W2^T w,  loss = w^T w.  pvec (2 nz + 1) is zeroed and not used.
+ * H of these systems is ill-conditioned (1e10 .. 1e12) -- the assembled form agrees with S^T S to 1e-14 relative and the steps to
+ * 1e-10 (tests/test_gpu_structured.py), inside the 1e-6 parity bound, but it is opt-in like every structured mode. */
 int gpk_gn_gram_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* G, int ldg, double* pvec);
 /* Darcy system: the iteration-independent part of the step, computed ONCE per factor (round 6).  The a-part rows of GN_loss,
  * [w1; w2; w0] against L_a (src/InverseProblems.py:137-146 of the reference), do not involve z_old: their block of A(z) is a

@@ -631,16 +631,23 @@ extern "C" int gpk_gn_gram_prepare(gpk_handle h, const gpk_gn_problem* p, double
     if (!h || !G || !pvec) return GPK_ERR_ARG;
     Dims d;
     GPK_TRY(check_prob(h, p, d));
-    if (p->system != GPK_GN_ELLIPTIC || !p->W1 || !p->W2 || !p->v0) return gpk_bad_arg(h, "gram_prepare: elliptic system with W1/W2/v0 only");
+    const bool elliptic = p->system == GPK_GN_ELLIPTIC;
+    if (p->system == GPK_GN_ELLIPTIC_RELAXED || !p->W1 || !p->W2 || (elliptic && !p->v0))
+        return gpk_bad_arg(h, "gram_prepare: needs W1/W2 (and v0 for the elliptic system) of gpk_gn_structured_prepare; not for the relaxed system");
     const int nz = d.nz;
     if (ldg < nz || p->ldw < nz + 1) return gpk_bad_arg(h, "gram_prepare: ldg/ldw");
     const double* Wm[2] = {p->W1, p->W2};
     for (int i = 0; i < 2; ++i)
         for (int j = 0; j < 2; ++j)                                  // Gij = Wi^T Wj (full blocks: the gemv reads rows of all four)
             GPK_TRY(gpk_i_gemm(h, true, false, nz, nz, d.rows, 1.0, Wm[i], p->ldw, Wm[j], p->ldw, 0.0, G + (long)(2 * i + j) * nz * ldg, ldg, false));
-    for (int i = 0; i < 2; ++i)                                      // p_i = Wi^T v0 (a one-column product)
-        GPK_TRY(gpk_i_gemm(h, true, false, nz, 1, d.rows, 1.0, Wm[i], p->ldw, p->v0, 1, 0.0, pvec + (long)i * nz, 1, false));
-    GPK_TRY(gpk_i_dot(h, p->v0, p->v0, d.rows, pvec + 2L * nz));
+    if (elliptic) {
+        for (int i = 0; i < 2; ++i)                                  // p_i = Wi^T v0 (a one-column product)
+            GPK_TRY(gpk_i_gemm(h, true, false, nz, 1, d.rows, 1.0, Wm[i], p->ldw, p->v0, 1, 0.0, pvec + (long)i * nz, 1, false));
+        GPK_TRY(gpk_i_dot(h, p->v0, p->v0, d.rows, pvec + 2L * nz));
+    } else {
+        // the other systems (round 6) solve the column w = L^{-1}F(z) every step and take the border from it: pvec is not used
+        GPK_HIP(h, hipMemsetAsync(pvec, 0, (2 * (size_t)nz + 1) * sizeof(double), h->stream));
+    }
     GPK_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -719,6 +726,9 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     LayoutScope layout_scope(h, p, rev);
     double* W = nullptr;                                             // the solved block [L^{-1}A | L^{-1}F] (S or the workspace)
     const bool gram = h->tune.structured && p->system == GPK_GN_ELLIPTIC && p->G && p->pvec && p->ldg >= nz;
+    // the same level for the Burgers / Eikonal / Darcy systems (round 6): H/2 = D G11 D + D G12 + G21 D + G22 from the Gram blocks of
+    // W1 = L^{-1}A1, W2 = L^{-1}A2; the border from the SOLVED column w = L^{-1}F(z): g/2 = D W1^T w + W2^T w, loss = w^T w
+    const bool gram_general = h->tune.structured && rev >= 2 && p->G && p->W1 && p->W2 && p->ldg >= nz && p->ldw >= nz + 1 && all_dinv(h, p, d);
     double* d_loss = h->d_scalars;
     bool exact = false, exact_late = false;                          // (d_scalars[8]: the loss by substitution, exact_loss*)
     GPK_HIP(h, hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
@@ -753,6 +763,39 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         GPK_LAUNCH_CHECK(h);
         if (h->tune.exact_loss) { exact = true; GPK_TRY(exact_loss(h, p, d, z)); }   // reported loss: true substitution (round 6), as in the plain branch
         GPK_PROF_MARK(h, 1);
+    } else if (gram_general) {
+        if (h->tune.exact_loss) {
+            exact = true;
+            exact_late = h->tune.exact_loss == 1 && h->pipe_g && !h->pipe_unavailable;
+            if (exact_late) GPK_TRY(exact_loss_build(h, p, d, z));
+            else GPK_TRY(exact_loss(h, p, d, z));
+        }
+        GPK_PROF_MARK(h, 0);
+        const int db = p->dinv_block;
+        double* ws = nullptr;                                        // [w (rows) | d (nz) | q1 (nz) | q2 (nz)]
+        GPK_TRY(gpk_i_workspace(h, ((size_t)d.rows + 3 * (size_t)nz + 16) * sizeof(double), &ws));
+        h->work_sig[0] = -1;
+        double* wv = ws;
+        double* dcol = ws + ((d.rows + 1) & ~1L);                    // (16-byte aligned)
+        double* q = dcol + nz;
+        structured_coeff_general_kernel<<<gpk_ceil_div(nz, 256), 256, 0, h->stream>>>(p->system, p->Nd, nz, rev, p->p0, p->p1, p->rhs_f, z, dcol);
+        GPK_LAUNCH_CHECK(h);
+        GPK_TRY(build(h, p, z, S, lds, nz, 0));                      // F(z) into column nz of S; w = L^{-1}F(z), one column per factor
+        for (int k = 0; k < d.ngroups; ++k) {
+            const Group& g = d.g[k];
+            if (g.n <= 0) continue;
+            if (g.L) GPK_TRY(gpk_i_trsm_left_dinv(h, g.L, g.Dinv, db, g.n, g.ldl, S + (long)g.off * lds + nz, lds, wv + g.off, 1, 1, 0, 0));
+            else GPK_HIP(h, hipMemcpy2DAsync(wv + g.off, 8, S + (long)g.off * lds + nz, (size_t)lds * 8, 8, g.n, hipMemcpyDeviceToDevice, h->stream));
+        }
+        GPK_PROF_MARK(h, 1);
+        GPK_TRY(gpk_i_gemm(h, true, false, nz, 1, d.rows, 1.0, p->W1, p->ldw, wv, 1, 0.0, q, 1, false));          // q1 = W1^T w
+        GPK_TRY(gpk_i_gemm(h, true, false, nz, 1, d.rows, 1.0, p->W2, p->ldw, wv, 1, 0.0, q + nz, 1, false));     // q2 = W2^T w
+        gram_form_kernel<<<nz + 1, 256, 0, h->stream>>>(nz, p->G, p->ldg, dcol, q, Hb, ldh);
+        GPK_LAUNCH_CHECK(h);
+        GPK_TRY(gpk_i_dot(h, wv, wv, d.rows, Hb + (long)nz * ldh + nz));
+        GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        h->pipe_tev_used = 0; h->prof_pipelined = 0;
+        GPK_TRY(gpk_i_potrf(h, Hb, nz + 1, ldh, 0));
     } else if (h->tune.structured && rev >= 2 && p->W1 && p->W2 && p->ldw >= nz + 1 && all_dinv(h, p, d)) {
         // structured solve of the Burgers / Eikonal / Darcy systems (round 6, gpk_gn_structured_prepare): W = W1 diag(d(z)) + W2 in one
         // memory-bound pass over all rows; the F column by its own one-column solve per factor (exact; rows without a factor copied)
@@ -792,7 +835,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
     }
     // Hb = W^T W and its Cholesky factor, pipelined by column blocks (gpk_factor.hip); d_loss = Hb[nz][nz] before factoring;
     // the last row of the factor is (L_H^{-1} g/2)^T
-    if (rev == 4) {
+    if (rev == 4 && !gram_general) {
         // Darcy: Hb = W_u^T W_u (u-part rows + the data rows below them, piecewise profile) + W_a^T W_a (the a-part's own staircase on
         // its sub-square of columns, its F column as a border row), then the factorisation
         const int Nd = p->Nd, nc = nz + 1;
@@ -825,7 +868,7 @@ extern "C" int gpk_gn_step(gpk_handle h, const gpk_gn_problem* p, double* z, dou
         if (h->prof) { GPK_HIP(h, hipEventRecord(h->pipe_tev[1], h->stream)); h->pipe_tev_used = 2; }
         GPK_HIP(h, hipMemcpyAsync(d_loss, Hb + (long)nz * ldh + nz, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
         GPK_TRY(gpk_i_potrf(h, Hb, nc, ldh, 0));
-    } else if (!gram) GPK_TRY(gpk_i_syrk_potrf(h, W, lds, d.rows, nz + 1, rev ? nz : 0, Hb, ldh, d_loss));
+    } else if (!gram && !gram_general) GPK_TRY(gpk_i_syrk_potrf(h, W, lds, d.rows, nz + 1, rev ? nz : 0, Hb, ldh, d_loss));
     GPK_PROF_MARK(h, 2);
     GPK_PROF_MARK(h, 3);
     // the chain of the exact loss: on the GEMM partition's stream from here on (pipelined phase: that stream's last product finished before the

@@ -95,7 +95,7 @@ class Darcy_flow2d(_GPEquation):
                 raise RuntimeError('call Gram_matrix() and Gram_Cholesky() first')
             self._prob = gpk.GNProblem(get_context(), 'Darcy_flow2d', self.N_domain, self.N_boundary, self.rhs_f, self.bdy_g,
                                        self._dL_u, p0=float(self.noise_level), data_u=self.data_u, L2=self._dL_a,
-                                       structured=min(int(os.environ.get('GPK_STRUCTURED', '0') or 0), 1))   # (opt-in, round 6: gpk_gn_structured_prepare)
+                                       structured=int(os.environ.get('GPK_STRUCTURED', '0') or 0))   # (opt-in, round 6: gpk_gn_structured_prepare / 2: + gpk_gn_gram_prepare)
         return self._prob
 
     # loss / grad_loss inherited (device); GN_loss restated on the host for API parity (reference :126-147)

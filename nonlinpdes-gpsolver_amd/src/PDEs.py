@@ -80,8 +80,7 @@ class _GPEquation(object):
             # [L^{-1}A(z) | L^{-1}F(z)] from them (gpk_gn_structured_prepare) -- same iterates, about half the time per step
             # (round 6: GPK_STRUCTURED=1 also for the Burgers and Eikonal systems, and the Darcy system in InverseProblems.py: A(z) = A1 diag(d(z)) + A2)
             structured = int(os.environ.get('GPK_STRUCTURED', '0') or 0)
-            if self._system != 'Nonlinear_elliptic':
-                structured = min(structured, 1)                   # (the Gram level exists for the elliptic system only)
+            # (2 = the Gram level: since round 6 for every system with a structured form)
             self._prob = gpk.GNProblem(get_context(), self._system, self.N_domain, self.N_boundary, self.rhs_f, self.bdy_g,
                                        self._dL, p0=p0, p1=p1, pen_lambda=lam, structured=structured)
         return self._prob

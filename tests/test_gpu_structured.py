@@ -82,6 +82,14 @@ def _run_structured_pair(system, make_prob, z0, nsteps, sysm, Ls, tol_pair, tol_
     zc, _ = _steps(ctx, structured, z0, nsteps)
     ctx.tune(40, 1)
     assert np.array_equal(zc, za)
+    # second level (round 6 for these systems): the bordered matrix assembled from the Gram blocks of W1, W2 -- no solve of A(z), no product.
+    # H is ill-conditioned here (1e10 .. 1e12): the assembled H agrees with S^T S to ~1e-14, the iterates to 1e-10 .. 1e-8
+    structured.prepare_gram()
+    assert structured.struct.G
+    zg, hg = _steps(ctx, structured, z0, nsteps)
+    assert np.linalg.norm(zg - za) <= max(100 * tol_pair, 1e-7) * np.linalg.norm(za), (system, 'gram', np.linalg.norm(zg - za) / np.linalg.norm(za))
+    assert np.linalg.norm(zg - sol_ref) <= 1e-6 * np.linalg.norm(sol_ref)
+    np.testing.assert_allclose(hg, hist_ref, rtol=1e-5)
     ctx.close()
 
 
