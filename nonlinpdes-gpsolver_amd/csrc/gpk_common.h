@@ -60,6 +60,7 @@ inline int gpk_stair_first_col(const GpkStair& st, int rows_end, int ncols) {
 // flip one switch at a time.  The product path never calls gpk_tune.  "key N" = the key of gpk_tune.
 struct GpkTune {
     int asm_pairs = 1;                  // key 47: 0 = one column point per lane (8-byte stores) always
+    int seq_left_looking = 0;           // key 56: 1 = left-looking rank-64 work inside the 512-blocks of the one-stream Cholesky (experiment, round 6; with key 48 = 2)
     int asm_nt = 0;                     // key 55: 1 = non-temporal 16-byte stores in the two-point evaluator (round 6 A/B, tools/assembly_store_ab.py)
     int dbg = 0;                        // 
     int mt_trsm = 0;                    // key 2: 

@@ -252,6 +252,7 @@ extern "C" int gpk_tune(gpk_handle h, int key, int value) {
         case 51: t.potrf_ob = value; return 0;
         case 52: t.exact_loss = value; return 0;
         case 54: t.potrf_lookahead = value; return 0;
+        case 56: t.seq_left_looking = value != 0; return 0;
         case 55: if (value < 0 || value > 3) return gpk_bad_arg(h, "gpk_tune: key 55 takes 0 .. 3"); t.asm_nt = value; return 0;
         default: return gpk_bad_arg(h, "gpk_tune: unknown key");
     }

@@ -1325,7 +1325,10 @@ static int potrf_seq(gpk_handle h, double* A, int n, int lda, int pivot_base) {
     const int OB = (h->tune.potrf_ob >= 64 && h->tune.potrf_ob % 64 == 0) ? h->tune.potrf_ob : 512;
     for (int k0 = 0; k0 < n; k0 += OB) {
         const int ob = (n - k0 < OB) ? n - k0 : OB;
-        GPK_TRY(gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, ob, lda, pivot_base + k0));
+        // (gpk_tune key 56, round-6 experiment: the left-looking form inside the block on the whole chip -- with the fused schedule forced,
+        // key 48 = 2, the extra workgroups of panel kernel j apply ALL finished panels of the block to the next panel's 64 columns (K = 64 j,
+        // rows/64 workgroups) instead of panel j-1 to all remaining columns (K = 64, up to 7 rows/64 workgroups))
+        GPK_TRY(gpk_i_potrf_panel(h, A + (long)k0 * lda + k0, n - k0, ob, lda, pivot_base + k0, h->tune.seq_left_looking != 0));
         const int rest = n - (k0 + ob);
         if (rest > 0) {
             double* P = A + (long)(k0 + ob) * lda + k0;               // factored panel rows below the outer block
