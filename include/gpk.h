@@ -246,8 +246,9 @@ int gpk_gn_darcy_prepare(gpk_handle h, const gpk_gn_problem* host_prob, double* 
 /* building blocks of gpk_gn_step for the column-sharded multi-GPU step: S <- [A(z) | F(z)] (no solve), y += alpha x */
 int gpk_gn_build(gpk_handle h, const gpk_gn_problem* host_prob, const double* z, double* S, int lds);
 /* Same with unknown j stored in column n_z-1-j (elliptic system): column c < n_z of [A | F] is then zero above row
- * n_z-1-c -- the layout gpk_gn_step uses internally and gpk_trsm_lz / gpk_gemm_lz exploit.  Round 6: also the Eikonal and Burgers
- * systems, in the staircase orders of THEIR gpk_gn_step (unknown groups v1, v2, v0 / the three unknowns of a point interleaved). */
+ * n_z-1-c -- the layout gpk_gn_step uses internally and gpk_trsm_lz / gpk_gemm_lz exploit.  Round 6: also the Eikonal, Burgers and
+ * Darcy systems, in the staircase orders of THEIR gpk_gn_step (unknown groups v1, v2, v0 / the three unknowns of a point interleaved /
+ * v1, v2, w1, w2, w0, v0). */
 int gpk_gn_build_rev(gpk_handle h, const gpk_gn_problem* p, const double* z, double* S, int lds);
 int gpk_axpy(gpk_handle h, int n, double alpha, const double* x, double* y);
 /* loss(z) (src/PDEs.py:82-87,278-289,418-430,138-147; src/InverseProblems.py:105-120); work: s_rows doubles. */

@@ -74,7 +74,8 @@ int gpk_mg_rccl_init(gpk_mg_handle mg, const char* librccl_path, const void* hos
  * holds from 4 ranks on for the work-balanced shards of BASELINE config 5 (widest / mean 1.57 at 4 ranks, 1.79 at 8);
  * 2 = DIRECT exchange: inside one ncclGroupStart / ncclGroupEnd every rank sends its shard to every peer and receives theirs (exact
  * sizes).  xGMI is point-to-point -- one link per peer -- so the world - 1 transfers of a rank use world - 1 links at once where a
- * ring collective is bound by one; the block rows of Hb are exchanged the same way.  Needs gpk_mg_has_p2p; bench.py times all forms) */
+ * ring collective is bound by one; the block rows of Hb are exchanged the same way.  Needs gpk_mg_has_p2p; bench.py times all forms);
+ * key 4: 0 = never use the point-to-point entry points even when they are bound (gpk_mg_has_p2p then answers 0; GPK_MG_P2P=0 in the Python layer) */
 int gpk_mg_set_option(gpk_mg_handle mg, int key, int value);
 
 /* Health check of the bound collectives (every rank calls it): a broadcast from rank 0 and an all-gather of small buffers,
@@ -94,7 +95,8 @@ int gpk_mg_preflight_p2p(gpk_mg_handle mg, size_t bytes, int reps, double* host_
 int gpk_mg_potrf(gpk_mg_handle mg, double* A, int n, int lda, int* host_info);
 
 /* gpk_gn_step over all ranks (elliptic system and, since round 6, the Eikonal and Burgers systems -- one factor each, the same column
- * shards cut by work under their own leading-zero profiles; Darcy and the relaxed system: one GPU only; host_prob->L = the replicated factor, host_prob->Dinv/dinv_block = its
+ * shards cut by work under their own leading-zero profiles -- and the Darcy system, which must carry its cached a-part (Wa / Ha of
+ * gpk_gn_darcy_prepare) and Dinv2: its u-part is sharded, the a-part and the data rows are replicated; the relaxed system: one GPU only; host_prob->L = the replicated factor, host_prob->Dinv/dinv_block = its
  * inverted diagonal blocks, gpk_trtri_diag).  S, S2: s_rows x lds each; S2 must be ZERO before the first step and is then
  * reused across steps (the solve never writes left of the leading-zero boundary).  z is updated identically on every rank.
  * world == 1: the call is gpk_gn_step itself (S2 unused), bit for bit. */

@@ -250,6 +250,8 @@ int gpk_i_gn_layout(gpk_handle h, const gpk_gn_problem* p);
 void gpk_i_gn_layout_enter(gpk_handle h, const gpk_gn_problem* p, int rev);
 void gpk_i_gn_layout_leave(gpk_handle h);
 int gpk_i_gn_first_row(gpk_handle h, int nz, int c);
+void gpk_i_gn_darcy_profile(gpk_handle h, int Nd);                   // the Darcy u-part's profile into gpk_ctx::stair (sharded step)
+int gpk_i_gn_darcy_add_a(gpk_handle h, const gpk_gn_problem* p, double* Hb, int ldh, int r0, int r1, const double* aF, int ldaf);
 int gpk_i_gn_exact_loss(gpk_handle h, const gpk_gn_problem* p, const double* z, double** d_out);   // gpk_tune key 52: loss(z) by substitution on h->stream
 int gpk_i_gn_finish(gpk_handle h, const gpk_gn_problem* p, int nz, int rev, const double* Hb, int ldh, double* scratch, double* delta,
                     double* z, double step_size);

@@ -956,7 +956,7 @@ extern "C" int gpk_gn_build_rev(gpk_handle h, const gpk_gn_problem* p, const dou
     if (!h || !z || !S || !p) return GPK_ERR_ARG;
     // (round 6: also the Eikonal and Burgers systems in the staircase orders of their gpk_gn_step -- the sharded step uses them)
     const int rev = step_layout(h, p);
-    if (rev < 1 || rev > 3 || p->system == GPK_GN_ELLIPTIC_RELAXED) return gpk_bad_arg(h, "gn_build_rev: elliptic, Eikonal and Burgers systems only");
+    if (rev < 1 || rev > 4 || p->system == GPK_GN_ELLIPTIC_RELAXED) return gpk_bad_arg(h, "gn_build_rev: not for the relaxed system / needs the leading-zero layout");
     Dims d;
     gpk_gn_problem q = *p;
     if (gn_dims(&q, d) != 0) return gpk_bad_arg(h, "gn: system id / sizes");
@@ -1003,6 +1003,37 @@ int gpk_i_gn_first_row(gpk_handle h, int nz, int c) {
     if (h->stair.nseg > 0) return gpk_stair_min(h->stair, c, c + 1);
     const int sd = h->lead_div > 0 ? h->lead_div : 1;
     return (nz - 1 - c) / sd;
+}
+
+// Darcy pieces of the sharded step (gpk_mg.hip): the u-part's three-segment profile into the handle (gpk_i_gn_layout_leave resets it) ...
+void gpk_i_gn_darcy_profile(gpk_handle h, int Nd) { h->stair = darcy_u_profile(Nd); h->stair_col0 = h->stair_row0 = 0; }
+
+// ... and the cached a-part added to the rows [r0, r1) of Hb a rank has just computed from the u-part and data rows: H_a on the rows that lie
+// in [N_d, 4 N_d) and, if row n_z is among them, the border terms (L_a^{-1}F_a)^T W_a and |L_a^{-1}F_a|^2 (aF: the solved a-part F column,
+// 3 N_d entries with stride ldaf) -- the launches of gpk_gn_step's rev = 4 branch, restricted to those rows
+__global__ __launch_bounds__(256) void add_lower_rows_kernel(int row0, const double* __restrict__ A, long lda, double* __restrict__ Cm, long ldc) {
+    const long i = row0 + blockIdx.x;                                 // row of the 3 N_d x 3 N_d lower triangle
+    const double* a = A + i * lda;
+    double* c = Cm + i * ldc;
+    for (int j = threadIdx.x; j <= (int)i; j += 256) c[j] += a[j];
+}
+
+int gpk_i_gn_darcy_add_a(gpk_handle h, const gpk_gn_problem* p, double* Hb, int ldh, int r0, int r1, const double* aF, int ldaf) {
+    const int Nd = p->Nd, na = 3 * Nd, nz = 6 * Nd;
+    const int a0 = std::max(r0, Nd), a1 = std::min(r1, 4 * Nd);
+    if (a1 > a0) {
+        add_lower_rows_kernel<<<a1 - a0, 256, 0, h->stream>>>(a0 - Nd, p->Ha, p->ldha, Hb + (long)Nd * ldh + Nd, ldh);
+        GPK_LAUNCH_CHECK(h);
+    }
+    if (r0 <= nz && nz < r1) {
+        const GpkStair keep = h->stair;                              // (closed-form staircase of the a-part's own columns, as on one GPU)
+        h->stair = GpkStair(); h->stair_col0 = h->stair_row0 = 0;
+        int rc = gpk_i_gemm(h, true, false, 1, na, na, 1.0, aF, ldaf, p->Wa, p->ldwa, 1.0, Hb + (long)nz * ldh + Nd, ldh, false, na);
+        if (rc == 0) rc = gpk_i_gemm(h, true, false, 1, 1, na, 1.0, aF, ldaf, aF, ldaf, 1.0, Hb + (long)nz * ldh + nz, ldh, false);
+        h->stair = keep;
+        GPK_TRY(rc);
+    }
+    return 0;
 }
 
 // n_z and the row count of the system handled by the sharded step

@@ -36,6 +36,7 @@ struct gpk_mg_ctx {
     gpk_mg_send_fn p2p_send = nullptr;     // ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd (optional: the direct exchange, key 3 = 2)
     gpk_mg_recv_fn p2p_recv = nullptr;
     gpk_mg_group_fn p2p_begin = nullptr, p2p_end = nullptr;
+    int p2p_off = 0;                       // gpk_mg_set_option key 4 = 0: behave as if the point-to-point entry points were not bound
     bool own_comm = false;
     void* lib = nullptr;
     int (*comm_destroy)(void*) = nullptr;
@@ -197,7 +198,7 @@ int ensure_buffers(gpk_mg_handle mg, size_t panel_bytes) {
 // doubles at `send` reach every peer's recv + off[r].  My own part is not moved.  Every rank issues the same group.
 int exchange_direct(gpk_mg_handle mg, const double* send, double* recv, const std::vector<size_t>& cnt, const std::vector<size_t>& off,
                     hipStream_t s, const char* what) {
-    if (!mg->p2p_send || !mg->p2p_recv || !mg->p2p_begin || !mg->p2p_end)
+    if (!gpk_mg_has_p2p(mg))
         return gpk_bad_arg(mg->h, "gpk_mg: the direct exchange needs ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd (gpk_mg_set_p2p)");
     const int P = mg->world, me = mg->rank;
     MG_NCCL(mg, mg->p2p_begin(), what);
@@ -424,13 +425,18 @@ extern "C" int gpk_mg_set_p2p(gpk_mg_handle mg, gpk_mg_send_fn send, gpk_mg_recv
     return 0;
 }
 
-extern "C" int gpk_mg_has_p2p(gpk_mg_handle mg) { return (mg && mg->p2p_send && mg->p2p_recv && mg->p2p_begin && mg->p2p_end) ? 1 : 0; }
+extern "C" int gpk_mg_has_p2p(gpk_mg_handle mg) { return (mg && !mg->p2p_off && mg->p2p_send && mg->p2p_recv && mg->p2p_begin && mg->p2p_end) ? 1 : 0; }
 
 extern "C" int gpk_mg_set_option(gpk_mg_handle mg, int key, int value) {
     if (!mg) return GPK_ERR_ARG;
     if (key == 0) { mg->lookahead = value != 0; return 0; }
     if (key == 1) { mg->shard_hb = value != 0; return 0; }
     if (key == 2 && value >= 1) { mg->col_align = value; return 0; }
+    if (key == 4) {                                                   // escape hatch: 0 = never use ncclSend / ncclRecv (falls back to the collectives)
+        mg->p2p_off = value == 0;
+        if (mg->p2p_off && mg->overlap_s == 2) mg->overlap_s = -1;
+        return 0;
+    }
     if (key == 3 && value >= -1 && value <= 2) {
         if (value == 2 && !gpk_mg_has_p2p(mg)) return gpk_bad_arg(mg->h, "gpk_mg_set_option: key 3 = 2 needs the point-to-point entry points (gpk_mg_set_p2p)");
         mg->overlap_s = value; return 0;
@@ -636,12 +642,15 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     gpk_handle h = mg->h;
     const int P = mg->world, rank = mg->rank, nb = mg->nb;
     if (P == 1) return gpk_gn_step(h, p, z, step_size, S, lds, Hb, ldh, delta, host_loss_in, host_info);
-    // round 6: the Eikonal and Burgers systems as well (one factor each), in the staircase orders of their gpk_gn_step; Darcy (two factors
-    // with different column supports) and the relaxed system are one-GPU only
+    // round 6: the Eikonal and Burgers systems as well (one factor each), in the staircase orders of their gpk_gn_step, and the Darcy system
+    // with its cached a-part (gpk_gn_darcy_prepare: only the u-part is sharded -- columns of L_u^{-1}A_u cut by work under its piecewise
+    // profile; the a-part contributes the constant H_a and one replicated F column).  The relaxed system is one-GPU only.
     const int rev = gpk_i_gn_layout(h, p);
-    if ((p->system != GPK_GN_ELLIPTIC && p->system != GPK_GN_EIKONAL && p->system != GPK_GN_BURGERS) || rev < 1 || rev > 3)
-        return gpk_bad_arg(h, "gpk_mg_gn_step: elliptic, Eikonal and Burgers systems only (leading-zero layout)");
+    const bool darcy = p->system == GPK_GN_DARCY;
+    if ((p->system != GPK_GN_ELLIPTIC && p->system != GPK_GN_EIKONAL && p->system != GPK_GN_BURGERS && !darcy) || rev < 1 || rev > 4 || (darcy != (rev == 4)))
+        return gpk_bad_arg(h, "gpk_mg_gn_step: elliptic, Eikonal, Burgers and Darcy systems only (leading-zero layout)");
     if (!p->Dinv || !S2) return gpk_bad_arg(h, "gpk_mg_gn_step: needs the inverted diagonal blocks (Dinv) and S2");
+    if (darcy && (!p->Wa || !p->Ha || !p->Dinv2)) return gpk_bad_arg(h, "gpk_mg_gn_step: the Darcy system needs its cached a-part (gpk_gn_darcy_prepare) and Dinv2");
     struct LayoutGuard {                                             // Eikonal: its profile in the handle; Burgers: the slope; reset on every way out
         gpk_handle h; LayoutGuard(gpk_handle hh, const gpk_gn_problem* pp, int r) : h(hh) { gpk_i_gn_layout_enter(h, pp, r); }
         ~LayoutGuard() { gpk_i_gn_layout_leave(h); }
@@ -658,16 +667,34 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     if (h->tune.exact_loss) GPK_TRY(gpk_i_gn_exact_loss(h, p, z, &d_exact));
     // ---- S <- [A | F] in the leading-zero layout on every rank (a memset + O(N)); my column shard of L^{-1}[A | F] -> S2
     GPK_TRY(gpk_gn_build_rev(h, p, z, S, lds));
+    // Darcy: rows [0, na) = a-part (factor L2, cached), [na, na + nu) = u-part (factor L: the sharded solve), then the data rows (no factor).
+    // Everything below works on the rows from `xoff` on: xrows of them are exchanged (the solved u-part), prows enter the products.
+    const int na = darcy ? 3 * p->Nd : 0, nu = darcy ? 4 * p->Nd + p->Nb : rows;
+    const int xoff = na, xrows = nu, prows = rows - na;
+    double* const Sx = S + (long)xoff * lds;
+    double* const S2x = S2 + (long)xoff * lds;
+    if (darcy) gpk_i_gn_darcy_profile(h, p->Nd);                      // the u-part's three-segment profile into the handle (reset by the guard)
     if (rev == 1) column_bounds(nc, nz, rows, P, mg->col_align, mg->bounds);
-    else column_bounds_by(nc, rows, P, mg->col_align, [&](int c) { return gpk_i_gn_first_row(h, nz, c); }, mg->bounds);
+    else column_bounds_by(nc, xrows, P, mg->col_align, [&](int c) { return gpk_i_gn_first_row(h, nz, c); }, mg->bounds);
     const std::vector<int>& b = mg->bounds;
     const int c0 = b[rank], c1 = b[rank + 1];
     int per = 0;
     for (int r = 0; r < P; ++r) per = std::max(per, b[r + 1] - b[r]);
     if (c1 > c0) {
         h->stair_base = c0;                                          // (piecewise profile: my shard's column 0 in the profile's frame)
-        const int rc = gpk_i_trsm_left_dinv(h, p->L, p->Dinv, db, rows, p->ldl, S + c0, lds, S2 + c0, lds, c1 - c0, std::max(nz - c0, 0), 0);
+        const int rc = gpk_i_trsm_left_dinv(h, p->L, p->Dinv, db, xrows, p->ldl, Sx + c0, lds, S2x + c0, lds, c1 - c0, darcy ? 1 : std::max(nz - c0, 0), 0);
         h->stair_base = 0; h->stair_col0 = h->stair_row0 = 0;        // (the products below read S2 from its column 0, row 0)
+        GPK_TRY(rc);
+    }
+    if (darcy) {
+        // replicated on every rank (tiny): the data rows (identity factor: all columns) and the a-part's F column L_a^{-1}[w1; w2; w0]
+        if (p->Ndata > 0)
+            GPK_HIP(h, hipMemcpy2DAsync(S2x + (long)nu * lds, (size_t)lds * 8, Sx + (long)nu * lds, (size_t)lds * 8, (size_t)nc * 8, (size_t)p->Ndata,
+                                        hipMemcpyDeviceToDevice, h->stream));
+        GpkStair keep = h->stair;                                    // (a dense one-column solve: no profile)
+        h->stair = GpkStair();
+        const int rc = gpk_i_trsm_left_dinv(h, p->L2, p->Dinv2, db, na, p->ldl2, S + nz, lds, S2 + nz, lds, 1, 0, 0);
+        h->stair = keep; h->stair_col0 = h->stair_row0 = 0;
         GPK_TRY(rc);
     }
     // ---- exchange of the column shards of S2, then my block rows (cyclic) of the lower triangle of Hb = S2^T S2 (structural zeros
@@ -676,7 +703,7 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     //      1: one BROADCAST per shard, in rank order, on the communication stream (exact sizes, no padding); block row i only needs the
     //         columns [0, i0 + ib), i.e. the shards up to the one that holds its last column -- its product is issued behind that
     //         shard's event, so the early block rows are computed while the later shards are still travelling.
-    const size_t shard = (size_t)rows * per;
+    const size_t shard = (size_t)xrows * per;
     const bool direct = mg->overlap_s == 2;                           // exact sizes, grouped point-to-point (round 6)
     const bool overlap_s = direct ? true : mg->overlap_s < 0 ? (long)(P - 1) * per > (long)nc : mg->overlap_s != 0;   // (a function of the shapes: all ranks agree; `true` also selects the exact-size packing)
     const int nblk = gpk_ceil_div(nc, nb), per_rank = gpk_ceil_div(nblk, P);
@@ -685,24 +712,29 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
     for (int i = 0; i < nblk; ++i) { const int i0 = i * nb, ib = std::min(nb, nc - i0); share[i % P] += (size_t)ib * (size_t)(i0 + ib); }
     const size_t hshare = *std::max_element(share.begin(), share.end());
     (void)per_rank;
-    const size_t all_s = overlap_s ? (size_t)rows * nc : shard * P;
+    const size_t all_s = overlap_s ? (size_t)xrows * nc : shard * P;
     GPK_TRY(ensure_gather(mg, std::max(shard, hshare) * sizeof(double), std::max(all_s, hshare * P) * sizeof(double)));
     if (c1 > c0)
-        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)(overlap_s ? c1 - c0 : per) * 8, S2 + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)rows,
+        GPK_HIP(h, hipMemcpy2DAsync(mg->gsend, (size_t)(overlap_s ? c1 - c0 : per) * 8, S2x + c0, (size_t)lds * 8, (size_t)(c1 - c0) * 8, (size_t)xrows,
                                     hipMemcpyDeviceToDevice, s));
     auto block_row = [&](int i) {
         const int i0 = i * nb, ib = std::min(nb, nc - i0);
-        return gpk_i_gemm(h, true, false, ib, i0 + ib, rows, 1.0, S2 + i0, lds, S2, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, nz);
+        h->stair_col0 = h->stair_row0 = 0;
+        int rc = gpk_i_gemm(h, true, false, ib, i0 + ib, prows, 1.0, S2x + i0, lds, S2x, lds, 0.0, Hb + (long)i0 * ldh, ldh, false, darcy ? 1 : nz);
+        // Darcy: + the cached a-part -- H_a on the rows of this block that lie in [N_d, 4 N_d), and in the block that holds the border row its
+        // a-part terms (L_a^{-1}F_a)^T W_a and |L_a^{-1}F_a|^2, exactly the launches of the one-GPU step
+        if (rc == 0 && darcy) rc = gpk_i_gn_darcy_add_a(h, p, Hb, ldh, i0, i0 + ib, S2 + nz, lds);
+        return rc;
     };
     if (direct) {
         std::vector<size_t> cnt((size_t)P), off((size_t)P);
         size_t o = 0;
-        for (int r = 0; r < P; ++r) { cnt[r] = (size_t)rows * (size_t)(b[r + 1] - b[r]); off[r] = o; o += cnt[r]; }
+        for (int r = 0; r < P; ++r) { cnt[r] = (size_t)xrows * (size_t)(b[r + 1] - b[r]); off[r] = o; o += cnt[r]; }
         GPK_TRY(exchange_direct(mg, mg->gsend, mg->grecv, cnt, off, s, "direct exchange of the shards of S"));
         for (int r = 0; r < P; ++r) {
             const int a0 = b[r], a1 = b[r + 1];
             if (r == rank || a1 <= a0) continue;
-            GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, mg->grecv + off[r], (size_t)(a1 - a0) * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+            GPK_HIP(h, hipMemcpy2DAsync(S2x + a0, (size_t)lds * 8, mg->grecv + off[r], (size_t)(a1 - a0) * 8, (size_t)(a1 - a0) * 8, (size_t)xrows,
                                         hipMemcpyDeviceToDevice, s));
         }
         for (int i = rank; i < nblk; i += P) GPK_TRY(block_row(i));
@@ -711,7 +743,7 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
         for (int r = 0; r < P; ++r) {
             const int a0 = b[r], a1 = b[r + 1];
             if (r == rank || a1 <= a0) continue;
-            GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, mg->grecv + (size_t)r * shard, (size_t)per * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+            GPK_HIP(h, hipMemcpy2DAsync(S2x + a0, (size_t)lds * 8, mg->grecv + (size_t)r * shard, (size_t)per * 8, (size_t)(a1 - a0) * 8, (size_t)xrows,
                                         hipMemcpyDeviceToDevice, s));
         }
         for (int i = rank; i < nblk; i += P) GPK_TRY(block_row(i));
@@ -723,12 +755,12 @@ extern "C" int gpk_mg_gn_step(gpk_mg_handle mg, const gpk_gn_problem* p, double*
         size_t off = 0;
         for (int r = 0; r < P; ++r) {                                // every rank issues the same broadcasts in the same order
             const int a0 = b[r], a1 = b[r + 1];
-            const size_t cnt = (size_t)rows * (size_t)(a1 - a0);
+            const size_t cnt = (size_t)xrows * (size_t)(a1 - a0);
             if (cnt > 0) {
                 double* dst = mg->grecv + off;
                 MG_NCCL(mg, mg->bcast(r == rank ? mg->gsend : dst, dst, cnt, NCCL_DOUBLE, r, mg->comm, (void*)cs), "broadcast of a shard of S");
                 if (r != rank)
-                    GPK_HIP(h, hipMemcpy2DAsync(S2 + a0, (size_t)lds * 8, dst, (size_t)(a1 - a0) * 8, (size_t)(a1 - a0) * 8, (size_t)rows,
+                    GPK_HIP(h, hipMemcpy2DAsync(S2x + a0, (size_t)lds * 8, dst, (size_t)(a1 - a0) * 8, (size_t)(a1 - a0) * 8, (size_t)xrows,
                                                 hipMemcpyDeviceToDevice, cs));
             }
             GPK_HIP(h, hipEventRecord(mg->ev[r], cs));

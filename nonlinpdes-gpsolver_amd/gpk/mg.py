@@ -95,6 +95,8 @@ class MultiGpu:
                 self._init_staged(group)
             elif self.world > 1:
                 raise ValueError("world > 1 needs comm='rccl' or comm='staged'")
+            if os.environ.get('GPK_MG_P2P', '1') == '0':             # escape hatch: never touch ncclSend / ncclRecv (direct exchange and its preflight off)
+                self.set_option('p2p', 0)
         except BaseException:
             # the object is never handed to the caller: release the native handle (and a half-made communicator) before re-raising
             # (_init_rccl raises on EVERY rank by design when any rank cannot bind RCCL; a caller's fall-back must not leak it)
@@ -247,7 +249,7 @@ class MultiGpu:
 
     # ---- options / calls ----------------------------------------------------------------------------------------------
     def set_option(self, key, value):
-        keys = {'lookahead': 0, 'shard_hb': 1, 'col_align': 2, 'overlap_s': 3}
+        keys = {'lookahead': 0, 'shard_hb': 1, 'col_align': 2, 'overlap_s': 3, 'p2p': 4}
         self.ctx._chk(self.lib.gpk_mg_set_option(self.h, keys[key] if isinstance(key, str) else int(key), int(value)))
 
     def selftest(self):

@@ -173,6 +173,8 @@ WORKER = textwrap.dedent('''
     sol_ref, hist_ref = O.gn_method(sysm, [Lref], z0, 3, 1)
     mgpu = MultiGpu(ctx, rank, world, panel=128, comm='staged')
     assert mgpu.selftest()
+    mgpu.set_option('p2p', 0); assert not mgpu.has_p2p()          # (round 6) the escape hatch of the direct exchange (GPK_MG_P2P=0)
+    mgpu.set_option('p2p', 1); assert mgpu.has_p2p()
     pf = mgpu.preflight(1 << 20, 1)                               # (round 5) the bandwidth preflight bench.py runs before a sharded run
     assert pf['ranks_seen_by_rccl'] == world and len(pf['bcast_ms_by_root']) == world
     assert all(m > 0 for m in pf['bcast_ms_by_root']) and pf['allgather_ms'] > 0 and all(v > 0 for v in pf['bcast_gbs_by_root'])
@@ -326,9 +328,19 @@ SYS_WORKER = textwrap.dedent('''
     mgpu = MultiGpu(ctx, rank, world, panel=128, comm='staged')
     mgpu.set_option('col_align', 64)
     out = {{}}
-    for system in ('Burgers', 'Eikonal'):
+    for system in ('Burgers', 'Eikonal', 'Darcy_flow2d'):
         rng = np.random.RandomState(31)
-        if system == 'Burgers':
+        if system == 'Darcy_flow2d':
+            Nd, Nb, Ndata = 230, 44, 17
+            Xd = rng.uniform(0, 1, (Nd, 2)); Xb = rng.uniform(0, 1, (Nb, 2))
+            f = np.ones(Nd); g = np.zeros(Nb)
+            data = 0.05 * np.sin(np.pi * Xd[:Ndata, 0]) * np.sin(np.pi * Xd[:Ndata, 1]) + 1e-3 * rng.normal(size=Ndata)
+            T, _ = ctx.assemble('Darcy_u', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+            Ta, _ = ctx.assemble('Darcy_a', 'Gaussian', 0.2, Xd, Xb, 1e-6, 'adaptive')
+            assert ctx.potrf(Ta) == 0
+            kw = dict(p0=1e-3, data_u=data, L2=Ta); sysm = O.DarcySystem(f, g, data, 1e-3); steps = 3
+            z0 = 0.3 * rng.normal(size=6 * Nd)
+        elif system == 'Burgers':
             Nd, Nb = 330, 61
             Xd = np.stack([rng.uniform(0, 1, Nd), rng.uniform(-1, 1, Nd)], axis=1)
             Xb = np.stack([rng.uniform(0, 1, Nb), rng.uniform(-1, 1, Nb)], axis=1)
@@ -345,7 +357,8 @@ SYS_WORKER = textwrap.dedent('''
             z0 = 0.1 * rng.normal(size=3 * Nd)
         assert ctx.potrf(T) == 0
         L = np.tril(T.download())
-        sol_ref, hist_ref = O.gn_method(sysm, [L], z0, steps, 1)
+        Ls = [np.tril(Ta.download()), L] if system == 'Darcy_flow2d' else [L]       # (oracle order: [L_a, L_u])
+        sol_ref, hist_ref = O.gn_method(sysm, Ls, z0, steps, 1)
         prob = gpk.GNProblem(ctx, system, Nd, Nb, f, g, T, dinv=256, **kw)
         one = ctx.array(z0)                                       # the one-GPU step of the same problem
         for _ in range(steps):
@@ -370,7 +383,6 @@ SYS_WORKER = textwrap.dedent('''
             res.append(zz)
         out[system] = np.stack(res)
         prob.release_workspace()
-    # Darcy stays a one-GPU system: the sharded entry point says so instead of computing something
     np.savez(os.path.join({out!r}, f'sys_{{rank}}.npz'), **out)
     dist.barrier()
     mgpu.close()
@@ -382,9 +394,10 @@ SYS_WORKER = textwrap.dedent('''
 
 @pytest.mark.parametrize('world', [2, 3])
 def test_native_sharded_step_of_the_burgers_and_eikonal_systems(world, tmp_path):
-    """Round 6: gpk_mg_gn_step for the Burgers (staircase of slope 1/3) and Eikonal (two-segment profile) systems -- column shards cut by
-    work under their own profiles, every exchange form, replicated and panel-sharded Cholesky of Hb -- against the oracle (<= 1e-6), the
-    one-GPU step (<= 1e-8) and across ranks (bit for bit).  Several ranks on ONE GPU, host-staged collectives."""
+    """Round 6: gpk_mg_gn_step for the Burgers (staircase of slope 1/3), Eikonal (two-segment profile) and Darcy (u-part sharded under its
+    three-segment profile, cached a-part, data rows) systems -- column shards cut by work under their own profiles, every exchange form,
+    replicated and panel-sharded Cholesky of Hb -- against the oracle (<= 1e-6), the one-GPU step (<= 1e-8) and across ranks (bit for bit).
+    Several ranks on ONE GPU, host-staged collectives."""
     script = tmp_path / 'worker.py'
     script.write_text(SYS_WORKER.format(root=ROOT, out=str(tmp_path)))
     port = _free_port()
@@ -396,5 +409,5 @@ def test_native_sharded_step_of_the_burgers_and_eikonal_systems(world, tmp_path)
     assert all(p.returncode == 0 for p in procs), [o[1][-3000:] for o in outs]
     zs = [np.load(tmp_path / f'sys_{r}.npz') for r in range(world)]
     for z in zs[1:]:
-        for k in ('Burgers', 'Eikonal'):
+        for k in ('Burgers', 'Eikonal', 'Darcy_flow2d'):
             assert np.array_equal(z[k], zs[0][k])
