@@ -98,7 +98,10 @@ def test_elliptic_relaxation_through_solver_gp(solves):
     assert _rel(s.eqn.sol_sampled_pts, d[p + '__sol']) < 1e-6
 
 
-def test_burgers_through_solver_gp(solves):
+@pytest.mark.parametrize('structured', ['0', '1', '2'])
+def test_burgers_through_solver_gp(solves, structured, monkeypatch):
+    # (round 6: GPK_STRUCTURED=1 / 2 -- the structured solve and its Gram level exist for this system too; same fixtures of the reference's own run, same bounds)
+    monkeypatch.setenv('GPK_STRUCTURED', structured)
     from src.solver import solver_GP
     d, p = solves, 'burgers_small'
     alpha, nu, st, sx, nug, steps, seed = d[p + '__params']
@@ -111,6 +114,7 @@ def test_burgers_through_solver_gp(solves):
     s.auto_sample(200, 60, print_option=False)
     assert s.eqn.N_boundary == 60 and np.array_equal(s.eqn.X_domain, d[p + '__X_domain'])
     s.solve(print_option=False)
+    assert (s.eqn._prob.W1 is not None) == (structured != '0') and (s.eqn._prob.G is not None) == (structured == '2')
     np.testing.assert_allclose(s.eqn.loss_hist, d[p + '__loss_hist'], rtol=1e-6)
     np.testing.assert_allclose(s.eqn.ratio, d[p + '__ratio'], rtol=1e-13)
     assert _rel(s.eqn.sol_sampled_pts, d[p + '__sol']) < 1e-6
@@ -119,7 +123,10 @@ def test_burgers_through_solver_gp(solves):
     assert s.eqn.Hessian_GN(s.eqn.init_sol).shape == (600, 600)
 
 
-def test_eikonal_through_solver_gp(solves):
+@pytest.mark.parametrize('structured', ['0', '1', '2'])
+def test_eikonal_through_solver_gp(solves, structured, monkeypatch):
+    # (round 6: GPK_STRUCTURED=1 / 2 -- the structured solve and its Gram level exist for this system too; same fixtures of the reference's own run, same bounds)
+    monkeypatch.setenv('GPK_STRUCTURED', structured)
     from src.solver import solver_GP
     d, p = solves, 'eikonal_small'
     eps, sigma, nug, steps, seed = d[p + '__params']
@@ -136,7 +143,10 @@ def test_eikonal_through_solver_gp(solves):
     assert _rel(s.eqn.extended_sol, d[p + '__extended_sol']) < 1e-6
 
 
-def test_darcy_through_solver_gp(solves):
+@pytest.mark.parametrize('structured', ['0', '1', '2'])
+def test_darcy_through_solver_gp(solves, structured, monkeypatch):
+    # (round 6: GPK_STRUCTURED=1 / 2 -- the structured solve and its Gram level exist for this system too; same fixtures of the reference's own run, same bounds)
+    monkeypatch.setenv('GPK_STRUCTURED', structured)
     from src.solver import solver_GP
     d, p = solves, 'darcy_small'
     sigma, nug, steps, seed, ndata, noise = d[p + '__params']
