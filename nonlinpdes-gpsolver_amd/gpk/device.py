@@ -213,6 +213,22 @@ class GNProblem:
                 a.free()
         self._S = self._H = self._delta = self._work = None
 
+    def free(self):
+        """Release everything this problem allocated (workspace, inverted diagonal blocks, the prepared operators of the structured modes,
+        the cached Darcy a-part, its copies of the right-hand sides); the factors L / L2 belong to the caller.  The struct is inert afterwards."""
+        self.release_workspace()
+        for name in ('Dinv', 'Dinv2', 'W1', 'W2', 'v0', 'G', 'pvec', 'Wa', 'Ha'):
+            a = getattr(self, name, None)
+            if a is not None:
+                a.free()
+            setattr(self, name, None)
+        for a in self.keep:
+            a.free()
+        self.keep = []
+        s = self.struct
+        s.Dinv = s.Dinv2 = s.W1 = s.W2 = s.v0 = s.G = s.pvec = s.Wa = s.Ha = None
+        s.rhs_f = s.bdy_g = s.data_u = None
+
 
 class Context:
     """One handle = one device + one stream.  Raises GpkError if the library or the device is missing."""

@@ -53,7 +53,7 @@ class Darcy_flow2d(_GPEquation):
                 a.free()
         p = self.__dict__.pop('_prob', None)
         if p is not None:
-            p.release_workspace()
+            p.free()                                           # (workspace, inverted blocks, prepared operators: everything but the factors)
         for name in ('_Theta_u_host', '_Theta_a_host', '_L_u_host', '_L_a_host'):
             self.__dict__.pop(name, None)
 

@@ -61,7 +61,7 @@ class _GPEquation(object):
                 a.free()
         p = self.__dict__.pop('_prob', None)
         if p is not None:
-            p.release_workspace()
+            p.free()                                           # (workspace, inverted blocks, prepared operators: everything but the factors)
         self.__dict__.pop('_Theta_host', None)
         self.__dict__.pop('_L_host', None)
 
