@@ -2,8 +2,10 @@
 """Benchmark of the hot path: Gauss-Newton steps/sec (+ L2 error) of the GP solver for NonLinElliptic2d on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU -- bench_launch.py; the parent never
+                                                            touches the GPU and relays rank 0's line as its last stdout line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+           bench.py --gpus N --steps K --warmup W          (the same ranks started by torchrun: WORLD_SIZE is set, nothing is re-launched)
 
 `value` at N = 1 is measured on BASELINE config 2 (N_domain=4000, N_boundary=400: the configuration the metric is quoted on, it
 fits one GPU); with N > 1 ranks `value` is the SHARDED BASELINE config 5 (N_domain=16000, Theta of order 34000: panel-sharded
