@@ -393,7 +393,7 @@ SYS_WORKER = textwrap.dedent('''
 
 
 @pytest.mark.parametrize('world', [2, 3])
-def test_native_sharded_step_of_the_burgers_and_eikonal_systems(world, tmp_path):
+def test_native_sharded_step_of_the_burgers_eikonal_and_darcy_systems(world, tmp_path):
     """Round 6: gpk_mg_gn_step for the Burgers (staircase of slope 1/3), Eikonal (two-segment profile) and Darcy (u-part sharded under its
     three-segment profile, cached a-part, data rows) systems -- column shards cut by work under their own profiles, every exchange form,
     replicated and panel-sharded Cholesky of Hb -- against the oracle (<= 1e-6), the one-GPU step (<= 1e-8) and across ranks (bit for bit).
