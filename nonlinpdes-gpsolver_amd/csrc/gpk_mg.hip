@@ -504,16 +504,30 @@ extern "C" int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok) {
     *host_ok = 0;
     if (!mg->bcast || !mg->allgather) return gpk_bad_arg(h, "gpk_mg_selftest: no communicator bound");
     const int P = mg->world, n = 1000;
+    const bool p2p = gpk_mg_has_p2p(mg) != 0;
     double* d = nullptr;
-    GPK_HIP(h, hipMalloc((void**)&d, (size_t)n * (P + 2) * sizeof(double)));
-    std::vector<double> host((size_t)n * (P + 2));
+    GPK_HIP(h, hipMalloc((void**)&d, (size_t)n * (P + 3) * sizeof(double)));
+    std::vector<double> host((size_t)n * (P + 3), -7.0);
     for (int i = 0; i < n; ++i) { host[i] = (mg->rank == 0) ? 1000.0 + i : -1.0; host[n + i] = 100.0 * mg->rank + 0.001 * i; }
     int rc = 0;
-    hipError_t e = hipMemcpyAsync(d, host.data(), (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    hipError_t e = hipMemcpyAsync(d, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
         int r = mg->bcast(d, d, (size_t)n, NCCL_DOUBLE, 0, mg->comm, (void*)h->stream);
         if (r == 0) r = mg->allgather(d + n, d + 2 * n, (size_t)n, NCCL_DOUBLE, mg->comm, (void*)h->stream);
         if (r != 0) rc = nccl_fail(mg, r, "self-test collective");
+    }
+    if (rc == 0 && e == hipSuccess && p2p) {
+        // (round 6) the point-to-point entry points: one group in which every rank sends its pattern to its right neighbour and receives the
+        // left neighbour's (one rank: to and from itself) -- argument order and type codes of ncclSend / ncclRecv, group start / end
+        const int to = (mg->rank + 1) % P, from = (mg->rank + P - 1) % P;
+        int r = mg->p2p_begin();
+        int r1 = 0;
+        if (r == 0) {
+            r1 = mg->p2p_send(d + n, (size_t)n, NCCL_DOUBLE, to, mg->comm, (void*)h->stream);
+            if (r1 == 0) r1 = mg->p2p_recv(d + (size_t)(P + 2) * n, (size_t)n, NCCL_DOUBLE, from, mg->comm, (void*)h->stream);
+            r = mg->p2p_end();
+        }
+        if (r1 != 0 || r != 0) rc = nccl_fail(mg, r1 ? r1 : r, "self-test send / recv");
     }
     if (rc == 0 && e == hipSuccess) e = hipMemcpyAsync(host.data(), d, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (rc == 0 && e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -524,6 +538,10 @@ extern "C" int gpk_mg_selftest(gpk_mg_handle mg, int* host_ok) {
     for (int i = 0; i < n && ok; ++i) ok = host[i] == 1000.0 + i;
     for (int r = 0; r < P && ok; ++r)
         for (int i = 0; i < n && ok; ++i) ok = host[(size_t)(2 + r) * n + i] == 100.0 * r + 0.001 * i;
+    if (p2p) {
+        const int from = (mg->rank + P - 1) % P;
+        for (int i = 0; i < n && ok; ++i) ok = host[(size_t)(P + 2) * n + i] == 100.0 * from + 0.001 * i;
+    }
     *host_ok = ok ? 1 : 0;
     return 0;
 }

@@ -220,6 +220,13 @@ class MultiGpu:
                     if hip.hipStreamSynchronize(st) != 0:
                         return 1
                 reqs, recvs, cache = [], [], {}
+                # (a rank talking to itself -- the self-test with one rank: a local copy, gloo has no send-to-self)
+                selfs = [o for o in ops if o[3] == rank]
+                ops = [o for o in ops if o[3] != rank]
+                for snd in [o for o in selfs if o[0] == 's']:
+                    for rcv in [o for o in selfs if o[0] == 'r' and o[2] == snd[2]]:
+                        if hip.hipMemcpy(rcv[1], snd[1], snd[2], 3) != 0:
+                            return 1
                 for kind, buf, nbytes, peer, _ in ops:
                     if kind == 's':
                         key = (buf, nbytes)

@@ -103,6 +103,15 @@ def test_rccl_binding_comes_up_with_one_rank():
     rc = ctx.lib.gpk_mg_preflight(h, 64 << 20, 2, bms, C.byref(ams), C.byref(seen))
     assert rc == 0 and seen.value == 1 and bms[0] > 0 and ams.value > 0, ctx.lib.gpk_last_error(ctx.h).decode()
     print(f'[rccl] preflight, one rank: broadcast of 64 MB {bms[0]:.3f} ms, all-gather {ams.value:.3f} ms')
+    # (round 6) the point-to-point entry points of the REAL library are bound by gpk_mg_rccl_init (ncclSend / ncclRecv / ncclGroupStart /
+    # ncclGroupEnd by dlsym) and an (empty, one rank) group goes through them; the escape hatch switches them off
+    assert ctx.lib.gpk_mg_has_p2p(h) == 1
+    pms = C.c_double()
+    rc = ctx.lib.gpk_mg_preflight_p2p(h, 64 << 20, 2, C.byref(pms))
+    assert rc == 0 and pms.value >= 0.0, ctx.lib.gpk_last_error(ctx.h).decode()
+    assert ctx.lib.gpk_mg_set_option(h, 3, 2) == 0                  # direct exchange selectable ...
+    assert ctx.lib.gpk_mg_set_option(h, 4, 0) == 0 and ctx.lib.gpk_mg_has_p2p(h) == 0
+    assert ctx.lib.gpk_mg_set_option(h, 3, 2) < 0                   # ... and refused once the entry points are switched off
     assert ctx.lib.gpk_mg_destroy(h) == 0
     ctx.close()
 
